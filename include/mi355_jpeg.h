@@ -1,0 +1,162 @@
+/* mi355_jpeg.h -- C ABI of the MI355X-native strict JPEG encode path.
+ *
+ * Drop-in boundary for the CPU encode path of rusty-electron/jpeg-encoder-opencl:
+ * the work JpegEncoderHost does between reading the PPM and discarding the scan
+ * bit string (reference src/OpenCLProject_JpegEncoder.cpp:59-225, stage library
+ * src/utils.cpp) runs as hand-written HIP kernels for gfx950 behind these entry
+ * points.  The reference has no FFI of its own -- its interface is the header
+ * pair src/utils.hpp + src/huffman.hpp -- so each entry point names the
+ * reference functions it replaces.  Plain pointers and sizes only; no
+ * allocation crosses the boundary; errors are negative ints (the reference
+ * prints to stdout and returns -1, utils.cpp:17-63, or is UB).
+ *
+ * Results are bit-identical to the reference CPU path (including its quirks,
+ * SURVEY.md Appendix A); there is NO CPU fallback: every compute entry point
+ * fails with MI355_E_NO_DEVICE / a HIP error when no gfx950 device is usable.
+ *
+ * Threading: a context is single-owner.  One context per GPU per host thread;
+ * contexts are independent.
+ */
+#ifndef MI355_JPEG_H
+#define MI355_JPEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_JPEG_ABI_VERSION 1
+
+typedef struct mi355_jpeg_ctx mi355_jpeg_ctx;
+
+enum mi355_jpeg_status {
+    MI355_OK = 0,
+    MI355_E_ARG = -1,        /* null pointer, zero size, pad wider than the image (reference UB, utils.cpp:215,226) */
+    MI355_E_NO_DEVICE = -2,  /* no usable HIP device / kernels not loadable */
+    MI355_E_CAPACITY = -3,   /* caller's output buffer too small */
+    MI355_E_CATEGORY = -4,   /* a DC size > 11 or AC size > 10: the reference reads past its tables
+                                (huffman.hpp:9-23,45-57) -- defined here as an error */
+    MI355_E_ALLOC = -5,      /* device or host allocation failed */
+    MI355_E_TABLE = -6,      /* malformed quantisation / Huffman table */
+    MI355_E_HIP = -100       /* MI355_E_HIP - hipError_t */
+};
+
+/* flags */
+#define MI355_F_CDS 1u       /* run the 2x2 chroma averaging (performCDS, utils.cpp:113-141).
+                                Set = reference behaviour; clear = "4:4:4 (no subsample)" build convention */
+#define MI355_F_DEFAULT MI355_F_CDS
+
+/* One Huffman table in the form the kernels consume: index (run<<4)|size,
+ * len 0 = no code (the reference's "NULL" strings), code right-aligned, len <= 17
+ * (huffman.hpp:92-98 holds seven 17-bit codes). */
+typedef struct mi355_huff_table {
+    uint32_t code[256];
+    uint8_t len[256];
+} mi355_huff_table;
+
+/* Per-stage device time of the last encode call, in milliseconds (HIP events on
+ * the call's stream).  Mirrors the role of CPUTelemetry (utils.hpp:65-75). */
+typedef struct mi355_jpeg_timings {
+    float transform_ms; /* CSC+CDS+pad+shift+transform+quant+zig-zag (utils.cpp:92-558) */
+    float size_ms;      /* per-unit bit lengths (RLE + code lengths, utils.cpp:572-653) */
+    float scan_ms;      /* exclusive prefix sum of unit lengths */
+    float emit_ms;      /* bit-string emission (HuffmanEncoder, utils.cpp:656-698) */
+    float total_ms;
+} mi355_jpeg_timings;
+
+/* ---- lifetime --------------------------------------------------------- */
+int mi355_jpeg_abi_version(void);
+const char *mi355_jpeg_strerror(int status);
+/* Number of usable devices (0 when there is none; never fails). */
+int mi355_jpeg_device_count(void);
+/* Creates a context on HIP device `device_id` with the reference's tables:
+ * quant_mat_lum/quant_mat_chrom (utils.hpp:42-62) and the four code tables of
+ * huffman.hpp (including the 17-bit entries). */
+int mi355_jpeg_create(int device_id, mi355_jpeg_ctx **ctx);
+void mi355_jpeg_destroy(mi355_jpeg_ctx *ctx);
+
+/* ---- tables (utils.hpp:42-62, huffman.hpp) ---------------------------- */
+/* qlum/qchrom: 64 entries, row-major [v][u] exactly like quant_mat_lum[8][8];
+ * values 1..65535.  Replaces the table arguments of performQuantization
+ * (utils.cpp:454). */
+int mi355_jpeg_set_quant(mi355_jpeg_ctx *ctx, const uint32_t qlum[64], const uint32_t qchrom[64]);
+/* Build convention (not in the reference): IJG quality scaling of the q=50
+ * tables, quality 1..100; 50 restores the reference tables. */
+int mi355_jpeg_set_quality(mi355_jpeg_ctx *ctx, int quality);
+/* table: 0 DC luma, 1 DC chroma, 2 AC luma, 3 AC chroma (DC_LUMA_HUFF_CODES ...
+ * AC_CHROMA_HUFF_CODES).  NULL restores the reference table. */
+int mi355_jpeg_set_huffman(mi355_jpeg_ctx *ctx, int table, const mi355_huff_table *t);
+int mi355_jpeg_get_quant(mi355_jpeg_ctx *ctx, uint32_t qlum[64], uint32_t qchrom[64]);
+int mi355_jpeg_get_huffman(mi355_jpeg_ctx *ctx, int table, mi355_huff_table *t);
+
+/* ---- geometry helpers (getNearest8x8ImageSize, utils.cpp:184-187) ------ */
+void mi355_jpeg_padded_size(uint32_t W, uint32_t H, uint32_t *W8, uint32_t *H8);
+/* Upper bound in bytes of one frame's packed scan bits (what to size `out` as). */
+size_t mi355_jpeg_scan_bound(uint32_t W, uint32_t H);
+
+/* ---- the hot path ------------------------------------------------------
+ * rgb: interleaved 8-bit RGB, W*H*3 bytes per frame, row-major, frames
+ * contiguous (what readPPMImage returns, utils.cpp:11-65).
+ * out: frame f's scan bits are written MSB-first from out + f*out_stride; the
+ * last partial byte is zero padded.  bits[f] receives the exact bit count (the
+ * length of the string HuffmanEncoder returns, utils.cpp:697).
+ *
+ * Replaces, per frame: performCSC, performCDS, copyToLargerImage,
+ * addReversedPadding, copyUIntToDoubleImage, substractfromAll, performDCT,
+ * performQuantization, everyMCUisnow2DArray, performZigZag, performRLE,
+ * HuffmanEncoder (src/OpenCLProject_JpegEncoder.cpp:59-225). */
+
+/* Host buffers in, host buffers out (PCIe both ways, synchronous). */
+int mi355_jpeg_encode_scan(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, uint32_t H,
+                           uint32_t n_frames, uint32_t flags, uint8_t *out, size_t out_stride,
+                           uint64_t *bits);
+
+/* Device buffers in, device buffers out, asynchronous on `stream` (a
+ * hipStream_t, NULL = default stream).  d_bits: device array of n_frames
+ * uint64.  Errors detected on the device (capacity, category) are reported by
+ * the next mi355_jpeg_sync(). */
+int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx *ctx, const void *d_rgb, uint32_t W, uint32_t H,
+                                  uint32_t n_frames, uint32_t flags, void *d_out,
+                                  size_t out_stride, uint64_t *d_bits, void *stream);
+/* Waits for `stream`, then returns the first device-side error of the calls
+ * issued since the previous sync (MI355_OK if none). */
+int mi355_jpeg_sync(mi355_jpeg_ctx *ctx, void *stream);
+
+/* Whole file: build-defined JFIF framing (the reference writes no container,
+ * SURVEY.md Appendix C) around the scan of ONE frame: SOI, APP0, DQT, SOF0
+ * (H1V1 x3), DHT, SOS, stuffed entropy bytes padded with 1s, EOI. */
+int mi355_jpeg_encode_jfif(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, uint32_t H,
+                           uint32_t flags, uint8_t *out, size_t cap, size_t *out_len);
+
+/* ---- stage probes (host buffers; one frame) ----------------------------
+ * Let every stage be parity-checked like the reference's per-stage dumps. */
+/* Samples entering the transform: after performCSC, performCDS and padding
+ * (utils.cpp:92-141,199-233); out: W8*H8*3 bytes interleaved like the
+ * reference's padded ppm_t. */
+int mi355_jpeg_probe_samples(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, uint32_t H,
+                             uint32_t flags, uint8_t *out);
+/* Quantised zig-zag coefficients in the reference's row order
+ * (zigzag_arr[chan*N + block][64], utils.cpp:482-558); out: 3*N*64 int16. */
+int mi355_jpeg_probe_coefficients(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, uint32_t H,
+                                  uint32_t flags, int16_t *out);
+/* Bits each unit contributes, scan order 3*block+chan; out: 3*N uint32. */
+int mi355_jpeg_probe_unit_bits(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, uint32_t H,
+                               uint32_t flags, uint32_t *out);
+/* Entropy-code caller-supplied coefficients (reference row order, int16) --
+ * performRLE + HuffmanEncoder alone (utils.cpp:572-698). */
+int mi355_jpeg_entropy_only(mi355_jpeg_ctx *ctx, const int16_t *zigzag, uint32_t n_blocks,
+                            uint8_t *out, size_t cap, uint64_t *bits);
+
+/* ---- measurement ------------------------------------------------------- */
+/* Enable per-stage HIP-event timing on the next encode calls (adds events on the
+ * stream; off by default). */
+int mi355_jpeg_set_profiling(mi355_jpeg_ctx *ctx, int on);
+/* Stage times of the last *_device or host encode call (waits for its events). */
+int mi355_jpeg_last_timings(mi355_jpeg_ctx *ctx, mi355_jpeg_timings *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_JPEG_H */

@@ -1,0 +1,247 @@
+"""MI355X-native strict JPEG encode path -- Python binding of the C ABI.
+
+The product is ``libmi355jpeg.so`` (hand-written HIP kernels for gfx950 behind
+``include/mi355_jpeg.h``).  This module is the thin ctypes layer that tests and
+``bench.py`` use; it holds no compute of its own and there is NO CPU fallback:
+if the library is missing or no gfx950 device is usable, calls raise.
+
+The directory name contains a hyphen, so import it with::
+
+    import importlib; jpeg = importlib.import_module("jpeg-encoder-opencl_amd")
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355jpeg.so")
+
+F_CDS = 1
+F_DEFAULT = F_CDS
+
+OK, E_ARG, E_NO_DEVICE, E_CAPACITY, E_CATEGORY, E_ALLOC, E_TABLE, E_HIP = 0, -1, -2, -3, -4, -5, -6, -100
+
+
+class HuffTable(C.Structure):
+    _fields_ = [("code", C.c_uint32 * 256), ("len", C.c_uint8 * 256)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("transform_ms", C.c_float), ("size_ms", C.c_float), ("scan_ms", C.c_float),
+                ("emit_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+class JpegError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("mi355_jpeg: %s (status %d)" % (msg, status))
+        self.status = status
+
+
+# Every symbol include/mi355_jpeg.h declares (tests check the library exports all).
+ABI_SYMBOLS = [
+    "mi355_jpeg_abi_version", "mi355_jpeg_strerror", "mi355_jpeg_device_count", "mi355_jpeg_create",
+    "mi355_jpeg_destroy", "mi355_jpeg_set_quant", "mi355_jpeg_set_quality", "mi355_jpeg_set_huffman",
+    "mi355_jpeg_get_quant", "mi355_jpeg_get_huffman", "mi355_jpeg_padded_size", "mi355_jpeg_scan_bound",
+    "mi355_jpeg_encode_scan", "mi355_jpeg_encode_scan_device", "mi355_jpeg_sync", "mi355_jpeg_encode_jfif",
+    "mi355_jpeg_probe_samples", "mi355_jpeg_probe_coefficients", "mi355_jpeg_probe_unit_bits",
+    "mi355_jpeg_entropy_only", "mi355_jpeg_set_profiling", "mi355_jpeg_last_timings",
+]
+
+_lib = None
+
+
+def build():
+    """Compile the HIP library in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JpegError(E_NO_DEVICE, "libmi355jpeg.so not built (run `make -C %s`)" % _HERE)
+        # PyTorch-ROCm ships its own libamdhip64.so.7; two HIP runtimes in one process
+        # cannot both own the GPU.  Loading torch first makes this library bind to the
+        # runtime torch uses (same SONAME), so torch tensors and our kernels share it.
+        if os.environ.get("MI355_JPEG_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64p, sz = C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.c_size_t
+        L.mi355_jpeg_abi_version.restype = C.c_int
+        L.mi355_jpeg_strerror.restype = C.c_char_p
+        L.mi355_jpeg_strerror.argtypes = [C.c_int]
+        L.mi355_jpeg_device_count.restype = C.c_int
+        L.mi355_jpeg_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.mi355_jpeg_destroy.argtypes = [vp]
+        L.mi355_jpeg_destroy.restype = None
+        L.mi355_jpeg_set_quant.argtypes = [vp, vp, vp]
+        L.mi355_jpeg_set_quality.argtypes = [vp, C.c_int]
+        L.mi355_jpeg_set_huffman.argtypes = [vp, C.c_int, C.POINTER(HuffTable)]
+        L.mi355_jpeg_get_quant.argtypes = [vp, vp, vp]
+        L.mi355_jpeg_get_huffman.argtypes = [vp, C.c_int, C.POINTER(HuffTable)]
+        L.mi355_jpeg_padded_size.argtypes = [u32, u32, C.POINTER(u32), C.POINTER(u32)]
+        L.mi355_jpeg_padded_size.restype = None
+        L.mi355_jpeg_scan_bound.argtypes = [u32, u32]
+        L.mi355_jpeg_scan_bound.restype = sz
+        L.mi355_jpeg_encode_scan.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, u64p]
+        L.mi355_jpeg_encode_scan_device.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, vp, vp]
+        L.mi355_jpeg_sync.argtypes = [vp, vp]
+        L.mi355_jpeg_encode_jfif.argtypes = [vp, vp, u32, u32, u32, vp, sz, C.POINTER(sz)]
+        L.mi355_jpeg_probe_samples.argtypes = [vp, vp, u32, u32, u32, vp]
+        L.mi355_jpeg_probe_coefficients.argtypes = [vp, vp, u32, u32, u32, vp]
+        L.mi355_jpeg_probe_unit_bits.argtypes = [vp, vp, u32, u32, u32, vp]
+        L.mi355_jpeg_entropy_only.argtypes = [vp, vp, u32, vp, sz, u64p]
+        L.mi355_jpeg_set_profiling.argtypes = [vp, C.c_int]
+        L.mi355_jpeg_last_timings.argtypes = [vp, C.POINTER(Timings)]
+        for name in ABI_SYMBOLS:
+            f = getattr(L, name)
+            if f.restype is C.c_int and name not in ("mi355_jpeg_abi_version", "mi355_jpeg_device_count"):
+                pass
+        _lib = L
+    return _lib
+
+
+def _check(status):
+    if status != OK:
+        raise JpegError(status, lib().mi355_jpeg_strerror(status).decode())
+
+
+def device_count():
+    return lib().mi355_jpeg_device_count()
+
+
+def scan_bound(W, H):
+    return lib().mi355_jpeg_scan_bound(W, H)
+
+
+class Encoder:
+    """One encode context on one GPU (single owner, like the C context)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().mi355_jpeg_create(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().mi355_jpeg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tables
+    def set_quant(self, qlum, qchrom):
+        qlum = np.ascontiguousarray(qlum, np.uint32).reshape(64)
+        qchrom = np.ascontiguousarray(qchrom, np.uint32).reshape(64)
+        _check(lib().mi355_jpeg_set_quant(self._h, qlum.ctypes.data, qchrom.ctypes.data))
+
+    def set_quality(self, quality):
+        _check(lib().mi355_jpeg_set_quality(self._h, quality))
+
+    def get_quant(self):
+        ql, qc = np.zeros(64, np.uint32), np.zeros(64, np.uint32)
+        _check(lib().mi355_jpeg_get_quant(self._h, ql.ctypes.data, qc.ctypes.data))
+        return ql, qc
+
+    def get_huffman(self, table):
+        t = HuffTable()
+        _check(lib().mi355_jpeg_get_huffman(self._h, table, C.byref(t)))
+        return np.array(t.code, np.uint32), np.array(t.len, np.uint8)
+
+    def set_huffman(self, table, code=None, length=None):
+        if code is None:
+            _check(lib().mi355_jpeg_set_huffman(self._h, table, None))
+            return
+        t = HuffTable()
+        for i in range(256):
+            t.code[i] = int(code[i])
+            t.len[i] = int(length[i])
+        _check(lib().mi355_jpeg_set_huffman(self._h, table, C.byref(t)))
+
+    # ---- hot path, host buffers
+    def encode_scan(self, rgb, flags=F_DEFAULT, cap=None):
+        """rgb: uint8 [H,W,3] or [n,H,W,3].  Returns (list of packed-bit arrays, list of bit counts)."""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        if rgb.ndim == 3:
+            rgb = rgb[None]
+        n, H, W, _ = rgb.shape
+        if cap is None:
+            cap = scan_bound(W, H)
+        out = np.zeros((n, cap), np.uint8)
+        bits = (C.c_uint64 * n)()
+        _check(lib().mi355_jpeg_encode_scan(self._h, rgb.ctypes.data, W, H, n, flags, out.ctypes.data,
+                                            cap, bits))
+        return [out[f, :(bits[f] + 7) // 8].copy() for f in range(n)], [int(b) for b in bits]
+
+    def encode_jfif(self, rgb, flags=F_DEFAULT):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        H, W, _ = rgb.shape
+        cap = 2 * scan_bound(W, H) + 4096
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t()
+        _check(lib().mi355_jpeg_encode_jfif(self._h, rgb.ctypes.data, W, H, flags, out.ctypes.data, cap,
+                                            C.byref(n)))
+        return out[:n.value].tobytes()
+
+    # ---- hot path, device buffers (raw pointers, e.g. torch tensor .data_ptr())
+    def encode_scan_device(self, d_rgb, W, H, n_frames, d_out, out_stride, d_bits, flags=F_DEFAULT, stream=0):
+        _check(lib().mi355_jpeg_encode_scan_device(self._h, d_rgb, W, H, n_frames, flags, d_out, out_stride,
+                                                   d_bits, stream))
+
+    def sync(self, stream=0):
+        _check(lib().mi355_jpeg_sync(self._h, stream))
+
+    # ---- stage probes
+    def probe_samples(self, rgb, flags=F_DEFAULT):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        H, W, _ = rgb.shape
+        W8, H8 = (W + 7) // 8 * 8, (H + 7) // 8 * 8
+        out = np.empty((H8, W8, 3), np.uint8)
+        _check(lib().mi355_jpeg_probe_samples(self._h, rgb.ctypes.data, W, H, flags, out.ctypes.data))
+        return out
+
+    def probe_coefficients(self, rgb, flags=F_DEFAULT):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        H, W, _ = rgb.shape
+        N = ((W + 7) // 8) * ((H + 7) // 8)
+        out = np.empty((3 * N, 64), np.int16)
+        _check(lib().mi355_jpeg_probe_coefficients(self._h, rgb.ctypes.data, W, H, flags, out.ctypes.data))
+        return out
+
+    def probe_unit_bits(self, rgb, flags=F_DEFAULT):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        H, W, _ = rgb.shape
+        N = ((W + 7) // 8) * ((H + 7) // 8)
+        out = np.empty(3 * N, np.uint32)
+        _check(lib().mi355_jpeg_probe_unit_bits(self._h, rgb.ctypes.data, W, H, flags, out.ctypes.data))
+        return out
+
+    def entropy_only(self, zigzag, cap=None):
+        zigzag = np.ascontiguousarray(zigzag, np.int16)
+        N = zigzag.shape[0] // 3
+        if cap is None:
+            cap = (3 * N * 1727 + 7) // 8 + 8
+        out = np.zeros(cap, np.uint8)
+        bits = C.c_uint64()
+        _check(lib().mi355_jpeg_entropy_only(self._h, zigzag.ctypes.data, N, out.ctypes.data, cap,
+                                             C.byref(bits)))
+        return out[:(bits.value + 7) // 8].copy(), bits.value
+
+    # ---- measurement
+    def set_profiling(self, on=True):
+        _check(lib().mi355_jpeg_set_profiling(self._h, int(on)))
+
+    def last_timings(self):
+        t = Timings()
+        _check(lib().mi355_jpeg_last_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Timings._fields_}

@@ -1,0 +1,740 @@
+// Hand-written HIP kernels (gfx950 / CDNA4) for the strict JPEG encode path.
+//
+// Pipeline per batch of frames (all device resident):
+//   k_transform  RGB u8 -> quantised zig-zag int16 coefficients          (fp64-VALU bound)
+//                fuses performCSC, performCDS, copyToLargerImage/addReversedPadding,
+//                copyUIntToDoubleImage, substractfromAll, performDCT, performQuantization,
+//                everyMCUisnow2DArray, performZigZag        (reference src/utils.cpp:92-558)
+//   k_unit_sizes per-unit bit counts + tile-local exclusive offsets     (performRLE + code lengths)
+//   k_tile_scan  exclusive scan of the tile sums per frame (64-bit)
+//   k_emit       bit-string emission at the scanned offsets              (HuffmanEncoder)
+//
+// Vocabulary: a *block* is one 8x8 pixel block; a *unit* is one (block, channel)
+// pair = one row of the reference's zigzag_arr; a *tile* is 64 consecutive blocks
+// of a frame in raster order (192 units, contiguous in the scan order
+// 3*block+chan of utils.cpp:665-695).
+//
+// Floating point: the transform must reproduce the reference's unfused, strictly
+// ordered fp64 arithmetic bit for bit => this file is compiled with
+// -ffp-contract=off and never uses fma() outside the compiler's own correctly
+// rounded division.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jpeg_device.h"
+#include "jpeg_tables.h"
+
+#pragma clang fp contract(off)
+
+namespace mi355 {
+
+// ----------------------------------------------------------------------------
+// constant tables
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ constexpr double cos_tab(int a, int k) {
+    constexpr double T[8][8] = MI355_COS_TABLE;
+    return T[a][k];
+}
+__device__ __forceinline__ constexpr int zigzag_nat(int k) {
+    constexpr uint8_t Z[64] = MI355_ZIGZAG_TABLE;
+    return Z[k];
+}
+__device__ __forceinline__ constexpr double csc_k(int chan, int i) {
+    constexpr double K[3][4] = MI355_CSC_TABLE;
+    return K[chan][i];
+}
+
+// ----------------------------------------------------------------------------
+// sample stage: performCSC (utils.cpp:92-110), performCDS (:113-141), mirror
+// padding (:199-233), for ONE output channel.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t csc1(uint32_t r, uint32_t g, uint32_t b, double k0, double k1,
+                                         double k2, double k3) {
+    // doubles, left to right, truncating cast (quirk Q1)
+    double v = (((k0 * (double)r) + (k1 * (double)g)) + (k2 * (double)b)) + k3;
+    return (uint32_t)(int)v;
+}
+
+__device__ __forceinline__ uint32_t csc_at(const uint8_t* __restrict__ f, uint32_t W, uint32_t x,
+                                           uint32_t y, double k0, double k1, double k2, double k3) {
+    const uint8_t* p = f + ((size_t)y * W + x) * 3;
+    return csc1(p[0], p[1], p[2], k0, k1, k2, k3);
+}
+
+// Value of padded pixel (px,py) of channel `chan` exactly as the reference forms
+// it: CDS runs on the UNPADDED image over complete 2x2 quads only (quirk Q2),
+// then the canvas is mirrored, right first, then bottom (quirk Q3).
+__device__ __forceinline__ uint32_t sample_generic(const uint8_t* __restrict__ f, const Geom& g,
+                                                   bool avg, uint32_t px, uint32_t py, double k0,
+                                                   double k1, double k2, double k3) {
+    uint32_t mx = px < g.W ? px : 2 * g.W - 1 - px;
+    uint32_t my = py < g.H ? py : 2 * g.H - 1 - py;
+    if (avg) {
+        uint32_t qx = mx & ~1u, qy = my & ~1u;
+        if (qx + 1 < g.W && qy + 1 < g.H) {
+            uint32_t s = csc_at(f, g.W, qx, qy, k0, k1, k2, k3) +
+                         csc_at(f, g.W, qx + 1, qy, k0, k1, k2, k3) +
+                         csc_at(f, g.W, qx, qy + 1, k0, k1, k2, k3) +
+                         csc_at(f, g.W, qx + 1, qy + 1, k0, k1, k2, k3);
+            return s >> 2;  // (uint8_t)(sum / 4.0)
+        }
+    }
+    return csc_at(f, g.W, mx, my, k0, k1, k2, k3);
+}
+
+// Loads the 64 samples of block (bx,by), channel `chan`, packed 4 per dword
+// (sample y*8+x in byte (y*8+x)&3 of pk[(y*8+x)>>2]).
+// FAST: every block of this wave lies inside the image and rows are 8-byte
+// aligned (W % 8 == 0, base 8-aligned): 24 coalescing-friendly 8-byte loads.
+template <bool FAST>
+__device__ __forceinline__ void load_samples(const uint8_t* __restrict__ f, const Geom& g, int chan,
+                                             bool avg, uint32_t bx, uint32_t by, uint32_t lane,
+                                             uint32_t* lds, uint32_t (&pk)[16]) {
+    const double k0 = csc_k(chan, 0), k1 = csc_k(chan, 1), k2 = csc_k(chan, 2), k3 = csc_k(chan, 3);
+    if constexpr (FAST) {
+#pragma unroll
+        for (int yp = 0; yp < 4; ++yp) {  // row pairs
+            uint32_t w[2][6];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint2* p = reinterpret_cast<const uint2*>(
+                    f + ((size_t)(by * 8 + yp * 2 + r) * g.W + bx * 8) * 3);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    uint2 v = p[j];
+                    w[r][2 * j] = v.x;
+                    w[r][2 * j + 1] = v.y;
+                }
+            }
+            uint32_t val[2][8];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    uint32_t c[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        int byte = 3 * x + k;
+                        c[k] = (w[r][byte >> 2] >> (8 * (byte & 3))) & 255u;
+                    }
+                    val[r][x] = csc1(c[0], c[1], c[2], k0, k1, k2, k3);
+                }
+            if (avg) {
+#pragma unroll
+                for (int x = 0; x < 8; x += 2) {
+                    uint32_t m = (val[0][x] + val[0][x + 1] + val[1][x] + val[1][x + 1]) >> 2;
+                    val[0][x] = val[0][x + 1] = val[1][x] = val[1][x + 1] = m;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    pk[(yp * 2 + r) * 2 + h] = val[r][4 * h] | (val[r][4 * h + 1] << 8) |
+                                               (val[r][4 * h + 2] << 16) | (val[r][4 * h + 3] << 24);
+        }
+    } else {
+        // Edge / unaligned waves: one sample at a time through LDS so that the
+        // register array is only ever indexed statically.
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            uint32_t v = 0;
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                int s = i * 4 + j;
+                uint32_t smp = sample_generic(f, g, avg, bx * 8 + (s & 7), by * 8 + (s >> 3), k0, k1,
+                                              k2, k3);
+                v |= smp << (8 * j);
+            }
+            lds[i * 64 + lane] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pk[i] = lds[i * 64 + lane];
+    }
+}
+
+// ----------------------------------------------------------------------------
+// The reference's in-place "DCT" (utils.cpp:314-348, quirk Q5), one lane per
+// unit, 64 doubles in registers.
+//
+// For u = 0..7, v = 0..7:   s = sum_{y,x in that order, from 0.0} (P[y][x]*C[x][u])*C[y][v]
+//                           s *= scale(u,v);  P[v][u] = s   (stored BEFORE the next step)
+//
+// Bit-exact savings used here (nothing is re-associated):
+//  * t[y][x] = P[y][x]*C[x][u] is formed once per u; inside the v loop only
+//    P[v][u] changes, so only t[v][u] is refreshed (the same product the
+//    reference forms again and again).
+//  * C[.][0] == 1.0 exactly, so products with it are the identity and skipped.
+// ----------------------------------------------------------------------------
+template <int U>
+__device__ __forceinline__ void chain_u_static(double (&P)[64]) {
+    double t[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) t[i] = (U == 0) ? P[i] : P[i] * cos_tab(i & 7, U);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        double s = 0.0;
+#pragma unroll
+        for (int y = 0; y < 8; ++y)
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+                s += (v == 0) ? t[y * 8 + x] : t[y * 8 + x] * cos_tab(y, v);
+        s *= (U == 0 && v == 0) ? kScale00 : ((U == 0 || v == 0) ? kScale0X : kScaleXX);
+        P[v * 8 + U] = s;
+        t[v * 8 + U] = (U == 0) ? s : s * cos_tab(U, U);
+    }
+}
+
+// Same iteration with a run-time (wave-uniform) u >= 1: keeps the code small
+// (one copy of the 8 unrolled v steps) at the price of a uniform branch per step
+// to pick the destination register.
+__device__ __forceinline__ void chain_u_dynamic(double (&P)[64], int u) {
+    double cx[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) cx[x] = cos_tab(x, u);
+    const double cuu = cos_tab(u, u);
+    double t[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) t[i] = P[i] * cx[i & 7];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        double s = 0.0;
+#pragma unroll
+        for (int y = 0; y < 8; ++y)
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+                s += (v == 0) ? t[y * 8 + x] : t[y * 8 + x] * cos_tab(y, v);
+        s *= (v == 0) ? kScale0X : kScaleXX;
+        const double tu = s * cuu;
+        switch (u) {
+#define MI355_CASE(c)     \
+    case c:               \
+        P[v * 8 + c] = s; \
+        t[v * 8 + c] = tu; \
+        break;
+            MI355_CASE(1)
+            MI355_CASE(2)
+            MI355_CASE(3)
+            MI355_CASE(4)
+            MI355_CASE(5)
+            MI355_CASE(6)
+            default:
+                P[v * 8 + 7] = s;
+                t[v * 8 + 7] = tu;
+                break;
+#undef MI355_CASE
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void chain(double (&P)[64]) {
+    chain_u_static<0>(P);
+    if constexpr (MODE == 0) {
+        chain_u_static<1>(P);
+        chain_u_static<2>(P);
+        chain_u_static<3>(P);
+        chain_u_static<4>(P);
+        chain_u_static<5>(P);
+        chain_u_static<6>(P);
+        chain_u_static<7>(P);
+    } else {
+#pragma unroll 1
+        for (int u = 1; u < 8; ++u) chain_u_dynamic(P, u);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// k_transform: one wave per (tile, channel); lane = block.
+// grid.x = tiles*3 (XCD-aware decode below), grid.y = frame.
+// coefs layout: [frame][tile][chan][32 coefficient pairs][64 lanes] uint32,
+//   low half = zig-zag coefficient 2p, high half = 2p+1 (int16 each), so that
+//   the wave's stores and the entropy kernels' loads are 256-byte coalesced rows.
+// ----------------------------------------------------------------------------
+template <int MODE, bool PROBE>
+__global__ void __launch_bounds__(64)
+    k_transform(Geom g, const uint8_t* __restrict__ rgb, const double* __restrict__ qd,
+                uint32_t* __restrict__ coefs, uint8_t* __restrict__ probe_samples) {
+    __shared__ uint32_t lds[16 * 64];
+    const uint32_t lane = threadIdx.x;
+    // XCD-aware decode: consecutive workgroup ids are dealt round-robin over the 8
+    // XCDs, so ids i, i+8, i+16 (same XCD) get the three channels of one tile and
+    // share its RGB bytes in that XCD's L2.  Speed only; any mapping is correct.
+    uint32_t id = blockIdx.x, tile, chan;
+    {
+        uint32_t full = (g.tiles / 8) * 24;  // ids covered by complete groups of 8 tiles
+        if (id < full) {
+            uint32_t grp = id / 24, w = id % 24;
+            tile = grp * 8 + (w & 7);
+            chan = w >> 3;
+        } else {
+            uint32_t r = id - full;
+            tile = (g.tiles / 8) * 8 + r / 3;
+            chan = r % 3;
+        }
+    }
+    const uint32_t frame = blockIdx.y;
+    const uint8_t* f = rgb + (size_t)frame * g.frame_stride;
+    const uint32_t b = tile * 64 + lane;
+    const bool active = b < g.N;
+    const uint32_t bc = active ? b : g.N - 1;
+    const uint32_t by = bc / g.nbx, bx = bc - by * g.nbx;
+    const bool avg = (chan != 0) && (g.flags & 1u);
+
+    // wave-uniform choice of the fast loader
+    bool interior = (bx * 8 + 8 <= g.W) && (by * 8 + 8 <= g.H);
+    const bool fast = g.fast_rows && __all(interior);
+
+    uint32_t pk[16];
+    if (chan == 0) {
+        if (fast)
+            load_samples<true>(f, g, 0, false, bx, by, lane, lds, pk);
+        else
+            load_samples<false>(f, g, 0, false, bx, by, lane, lds, pk);
+    } else if (chan == 1) {
+        if (fast)
+            load_samples<true>(f, g, 1, avg, bx, by, lane, lds, pk);
+        else
+            load_samples<false>(f, g, 1, avg, bx, by, lane, lds, pk);
+    } else {
+        if (fast)
+            load_samples<true>(f, g, 2, avg, bx, by, lane, lds, pk);
+        else
+            load_samples<false>(f, g, 2, avg, bx, by, lane, lds, pk);
+    }
+
+    if constexpr (PROBE) {
+        // stage probe: the padded YCbCr image, interleaved like the reference's ppm_t
+        if (active) {
+#pragma unroll
+            for (int s = 0; s < 64; ++s) {
+                uint32_t v = (pk[s >> 2] >> (8 * (s & 3))) & 255u;
+                size_t px = (size_t)(by * 8 + (s >> 3)) * g.W8 + bx * 8 + (s & 7);
+                probe_samples[((size_t)frame * g.W8 * g.H8 + px) * 3 + chan] = (uint8_t)v;
+            }
+        }
+        return;
+    }
+
+    // level shift (substractfromAll(...,128.0), all three channels, quirk Q4)
+    double P[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s)
+        P[s] = (double)((int)((pk[s >> 2] >> (8 * (s & 3))) & 255u) - 128);
+
+    chain<MODE>(P);
+
+    // performQuantization (utils.cpp:457-463): correctly rounded divide, round half
+    // away from zero; luma table for channel 0, chroma for 1 and 2.
+    const double* q = qd + (chan ? 64 : 0);
+    int qi[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) qi[i] = (int)__builtin_round(P[i] / q[i]);
+
+    uint32_t* dst = coefs + (((size_t)frame * g.tiles + tile) * 3 + chan) * 2048 + lane;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        uint32_t lo = (uint32_t)qi[zigzag_nat(2 * p)] & 0xffffu;
+        uint32_t hi = (uint32_t)qi[zigzag_nat(2 * p + 1)] << 16;
+        dst[p * 64] = active ? (lo | hi) : 0u;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// entropy helpers
+// ----------------------------------------------------------------------------
+// Size category = bit length of |v| with v narrowed to int16 (getValueCategory,
+// utils.cpp:623-627).
+__device__ __forceinline__ int bit_size(int v) {
+    int a = v < 0 ? -v : v;
+    return 32 - __clz(a);  // __clz(0) == 32
+}
+// Value bits (valueToBitString, utils.cpp:630-653): v, or v + 2^size - 1 for v < 0.
+__device__ __forceinline__ uint32_t value_bits(int v, int size) {
+    return (uint32_t)(v < 0 ? v + (1 << size) - 1 : v);
+}
+
+// Device Huffman LUT entry: code << 5 | len  (len <= 17, code < 2^17).
+// lut layout: [table 0..3][256], index (run << 4) | size.
+__device__ __forceinline__ uint32_t lut_len(uint32_t e) { return e & 31u; }
+__device__ __forceinline__ uint32_t lut_code(uint32_t e) { return e >> 5; }
+
+// Walks one unit's 63 AC coefficients (RLEBlockAC, utils.cpp:572-609 fused with
+// the AC loop of HuffmanEncoder, :683-694) and calls put(code, len) for every
+// symbol incl. value bits.  `c` = 32 packed coefficient pairs.
+// Returns false if a size category has no code (quirk Q13 -> error).
+template <typename Put>
+__device__ __forceinline__ bool walk_ac(const uint32_t (&c)[32], const uint32_t* __restrict__ act,
+                                        Put&& put) {
+    bool ok = true;
+    int run = 0;
+    const uint32_t zrl = act[0xF0], eob = act[0x00];
+#pragma unroll
+    for (int k = 1; k < 64; ++k) {
+        int v = (int)(int16_t)((k & 1) ? (c[k >> 1] >> 16) : (c[k >> 1] & 0xffffu));
+        if (v == 0) {
+            ++run;
+        } else {
+            while (run >= 16) {  // the reference emits (15,0) at every 16th zero before a later non-zero
+                put(lut_code(zrl), lut_len(zrl));
+                run -= 16;
+            }
+            int size = bit_size(v);
+            uint32_t e = (size <= 10) ? act[(run << 4) | size] : 0u;
+            if (lut_len(e) == 0) {
+                ok = false;
+            } else {
+                put((lut_code(e) << size) | value_bits(v, size), lut_len(e) + size);
+            }
+            run = 0;
+        }
+    }
+    put(lut_code(eob), lut_len(eob));  // ALWAYS (quirk Q8)
+    return ok;
+}
+
+// DC symbol (utils.cpp:665-680).
+template <typename Put>
+__device__ __forceinline__ bool put_dc(int diff, const uint32_t* __restrict__ dct, Put&& put) {
+    int d = (int)(int16_t)diff;  // argument narrowed to int16_t
+    int size = bit_size(d);
+    uint32_t e = (size <= 11) ? dct[size] : 0u;
+    if (lut_len(e) == 0) return false;
+    put((lut_code(e) << size) | value_bits(d, size), lut_len(e) + size);
+    return true;
+}
+
+__device__ __forceinline__ void load_unit(const uint32_t* __restrict__ src, uint32_t (&c)[32]) {
+#pragma unroll
+    for (int p = 0; p < 32; ++p) c[p] = src[p * 64];
+}
+
+// DC predictor of lane's block = DC of the previous block of the same channel
+// (never reset inside a frame, utils.cpp:665-671); 0 for the first block.
+__device__ __forceinline__ int dc_predictor(const uint32_t* __restrict__ coefs_frame, uint32_t tile,
+                                            uint32_t chan, uint32_t lane, int own_dc) {
+    int prev = __shfl_up(own_dc, 1);
+    if (lane == 0) {
+        prev = 0;
+        if (tile > 0)
+            prev = (int)(int16_t)(coefs_frame[((size_t)(tile - 1) * 3 + chan) * 2048 + 63] & 0xffffu);
+    }
+    return prev;
+}
+
+// ----------------------------------------------------------------------------
+// k_unit_sizes: workgroup = one tile = 3 waves (wave = channel), lane = block.
+// Writes unit_off[frame][tile][192] (exclusive, tile-local, scan order
+// 3*block+chan) and tile_bits[frame][tile].
+// ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(192)
+    k_unit_sizes(Geom g, const uint32_t* __restrict__ coefs, const uint32_t* __restrict__ lut,
+                 uint32_t* __restrict__ unit_off, uint32_t* __restrict__ tile_bits,
+                 uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_lut[2][256];
+    __shared__ uint32_t s_dc[2][16];
+    __shared__ uint32_t s_bits[192];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
+    const uint32_t tile = blockIdx.x, frame = blockIdx.y;
+    for (uint32_t i = tid; i < 512; i += 192) s_lut[i >> 8][i & 255] = lut[512 + i];  // AC luma, AC chroma
+    if (tid < 32) s_dc[tid >> 4][tid & 15] = lut[(tid >> 4) * 256 + (tid & 15)];       // DC luma, DC chroma
+    __syncthreads();
+
+    const uint32_t* cf = coefs + (size_t)frame * g.tiles * 3 * 2048;
+    const uint32_t b = tile * 64 + lane;
+    const bool active = b < g.N;
+    uint32_t c[32];
+    load_unit(cf + ((size_t)tile * 3 + chan) * 2048 + lane, c);
+    const int dc = (int)(int16_t)(c[0] & 0xffffu);
+    const int pred = dc_predictor(cf, tile, chan, lane, dc);
+
+    uint32_t bits = 0;
+    auto count = [&](uint32_t, uint32_t len) { bits += len; };
+    bool ok = put_dc(dc - pred, s_dc[chan ? 1 : 0], count);
+    ok &= walk_ac(c, s_lut[chan ? 1 : 0], count);
+    if (!active) {
+        bits = 0;
+        ok = true;
+    }
+    if (!ok) atomicOr(status, 1u);  // MI355_E_CATEGORY
+
+    s_bits[lane * 3 + chan] = bits;
+    __syncthreads();
+    if (tid < 64) {
+        uint32_t a0 = s_bits[tid * 3], a1 = s_bits[tid * 3 + 1], a2 = s_bits[tid * 3 + 2];
+        uint32_t blk = a0 + a1 + a2, incl = blk;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t n = __shfl_up(incl, d);
+            if ((int)tid >= d) incl += n;
+        }
+        uint32_t excl = incl - blk;
+        uint32_t* uo = unit_off + ((size_t)frame * g.tiles + tile) * 192 + tid * 3;
+        uo[0] = excl;
+        uo[1] = excl + a0;
+        uo[2] = excl + a0 + a1;
+        if (tid == 63) tile_bits[(size_t)frame * g.tiles + tile] = incl;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// k_tile_scan: one workgroup per frame; exclusive 64-bit scan of the tile sums.
+// Also zeroes every output word that two tiles share (k_emit ORs into those),
+// writes the frame's bit count and checks the caller's capacity.
+// ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    k_tile_scan(Geom g, const uint32_t* __restrict__ tile_bits, uint64_t* __restrict__ tile_off,
+                uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ frame_bits,
+                uint32_t* __restrict__ status) {
+    __shared__ uint64_t s_wave[4];
+    __shared__ uint64_t s_carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t frame = blockIdx.x;
+    const uint32_t* tb = tile_bits + (size_t)frame * g.tiles;
+    uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
+    uint32_t* outw = reinterpret_cast<uint32_t*>(out + (size_t)frame * out_stride);
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < g.tiles; base += 256) {
+        uint32_t i = base + tid;
+        uint64_t v = i < g.tiles ? tb[i] : 0, incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t n = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += n;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint64_t pre = s_carry;
+        for (uint32_t w = 0; w < wave; ++w) pre += s_wave[w];
+        uint64_t excl = pre + incl - v;
+        if (i < g.tiles) {
+            to[i] = excl;
+            // word shared with the previous tile: both sides OR into it
+            if (i > 0 && (excl & 31) && (excl >> 5) * 4 + 4 <= out_stride) outw[excl >> 5] = 0;
+        }
+        __syncthreads();
+        if (tid == 255) s_carry = pre + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint64_t total = s_carry;
+        to[g.tiles] = total;
+        frame_bits[frame] = total;
+        if (((total + 31) >> 5) * 4 > out_stride) atomicOr(status, 2u);  // MI355_E_CAPACITY
+    }
+}
+
+// ----------------------------------------------------------------------------
+// k_emit: workgroup = one tile (3 waves = 3 channels, lane = block).  The tile's
+// 192 units are contiguous in the scan, so its bits are assembled in LDS
+// (big-endian 32-bit words, LDS atomic OR) and written out as coalesced words;
+// only the first / last word can be shared with a neighbour tile (global atomic
+// OR into words zeroed by k_tile_scan).  A tile whose bits do not fit the LDS
+// window takes the direct-to-global path.
+// ----------------------------------------------------------------------------
+constexpr uint32_t kEmitLdsWords = 4096;  // 16 KiB = 131072 bits = 682 bits per unit on average
+
+struct BitWriterLds {
+    uint32_t* words;  // LDS
+    uint64_t acc;     // right-aligned pending bits
+    uint32_t n;       // pending bit count (< 32 after every put)
+    uint32_t w;       // next word index
+    __device__ __forceinline__ void put(uint32_t code, uint32_t len) {
+        acc = (acc << len) | code;
+        n += len;
+        if (n >= 32) {
+            n -= 32;
+            atomicOr(&words[w++], (uint32_t)(acc >> n));
+            acc &= (1ull << n) - 1;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        if (n) atomicOr(&words[w], (uint32_t)(acc << (32 - n)));
+    }
+};
+
+struct BitWriterGlobal {
+    uint32_t* words;  // global, word index relative to the frame's output
+    uint64_t acc;
+    uint32_t n;
+    uint64_t w;
+    __device__ __forceinline__ void put(uint32_t code, uint32_t len) {
+        acc = (acc << len) | code;
+        n += len;
+        if (n >= 32) {
+            n -= 32;
+            atomicOr(&words[w++], __builtin_bswap32((uint32_t)(acc >> n)));
+            acc &= (1ull << n) - 1;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        if (n) atomicOr(&words[w], __builtin_bswap32((uint32_t)(acc << (32 - n))));
+    }
+};
+
+__global__ void __launch_bounds__(192)
+    k_emit(Geom g, const uint32_t* __restrict__ coefs, const uint32_t* __restrict__ lut,
+           const uint32_t* __restrict__ unit_off, const uint64_t* __restrict__ tile_off,
+           uint8_t* __restrict__ out, uint64_t out_stride, const uint32_t* __restrict__ status,
+           uint32_t lds_words_limit) {
+    __shared__ uint32_t s_lut[2][256];
+    __shared__ uint32_t s_dc[2][16];
+    __shared__ uint32_t s_words[kEmitLdsWords];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
+    const uint32_t tile = blockIdx.x, frame = blockIdx.y;
+    if (*status) return;  // a size had no code / capacity exceeded: nothing is emitted
+
+    const uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
+    const uint64_t start = to[tile], end = to[tile + 1];
+    const uint64_t w0 = start >> 5;                  // first output word of this tile
+    const uint32_t nw = (uint32_t)(((end + 31) >> 5) - w0);  // words touched
+    const bool use_lds = nw <= lds_words_limit;
+    uint32_t* outw = reinterpret_cast<uint32_t*>(out + (size_t)frame * out_stride);
+    const bool last_tile = tile + 1 == g.tiles;
+
+    for (uint32_t i = tid; i < 512; i += 192) s_lut[i >> 8][i & 255] = lut[512 + i];
+    if (tid < 32) s_dc[tid >> 4][tid & 15] = lut[(tid >> 4) * 256 + (tid & 15)];
+    if (use_lds) {
+        for (uint32_t i = tid; i < nw; i += 192) s_words[i] = 0;
+    } else {
+        // direct path: every word of the tile is ORed into, so zero the words this
+        // tile owns exclusively (shared boundary words were zeroed by k_tile_scan)
+        for (uint32_t i = tid; i < nw; i += 192) {
+            bool shared = (i == 0 && (start & 31)) || (i == nw - 1 && (end & 31) && !last_tile);
+            if (!shared) __hip_atomic_store(&outw[w0 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+
+    const uint32_t* cf = coefs + (size_t)frame * g.tiles * 3 * 2048;
+    const uint32_t b = tile * 64 + lane;
+    if (b < g.N) {
+        uint32_t c[32];
+        load_unit(cf + ((size_t)tile * 3 + chan) * 2048 + lane, c);
+        const int dc = (int)(int16_t)(c[0] & 0xffffu);
+        const int pred = dc_predictor(cf, tile, chan, lane, dc);
+        const uint32_t off = unit_off[((size_t)frame * g.tiles + tile) * 192 + lane * 3 + chan];
+        const uint64_t pos = (start & 31) + off;  // bit position relative to word w0
+        if (use_lds) {
+            BitWriterLds bw{s_words, 0, (uint32_t)(pos & 31), (uint32_t)(pos >> 5)};
+            auto put = [&](uint32_t code, uint32_t len) { bw.put(code, len); };
+            put_dc(dc - pred, s_dc[chan ? 1 : 0], put);
+            walk_ac(c, s_lut[chan ? 1 : 0], put);
+            bw.flush();
+        } else {
+            BitWriterGlobal bw{outw, 0, (uint32_t)(pos & 31), w0 + (pos >> 5)};
+            auto put = [&](uint32_t code, uint32_t len) { bw.put(code, len); };
+            put_dc(dc - pred, s_dc[chan ? 1 : 0], put);
+            walk_ac(c, s_lut[chan ? 1 : 0], put);
+            bw.flush();
+        }
+    }
+    if (!use_lds) return;
+    __syncthreads();
+    for (uint32_t i = tid; i < nw; i += 192) {
+        uint32_t v = __builtin_bswap32(s_words[i]);
+        bool shared = (i == 0 && (start & 31)) || (i == nw - 1 && (end & 31) && !last_tile);
+        if (shared) {
+            if (v) atomicOr(&outw[w0 + i], v);
+        } else {
+            outw[w0 + i] = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// layout converters for the stage probes (not on the hot path)
+// ----------------------------------------------------------------------------
+// tiled coefs -> reference row order int16 [chan*N + block][64]
+__global__ void k_coefs_to_rows(Geom g, const uint32_t* __restrict__ coefs, int16_t* __restrict__ rows) {
+    uint32_t unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // chan*N + block
+    uint32_t k = threadIdx.x & 63;
+    if (unit >= 3 * g.N) return;
+    uint32_t chan = unit / g.N, b = unit - chan * g.N;
+    uint32_t tile = b >> 6, lane = b & 63;
+    uint32_t w = coefs[((size_t)tile * 3 + chan) * 2048 + (k >> 1) * 64 + lane];
+    rows[(size_t)unit * 64 + k] = (int16_t)((k & 1) ? (w >> 16) : (w & 0xffffu));
+}
+// reference row order int16 -> tiled coefs
+__global__ void k_rows_to_coefs(Geom g, const int16_t* __restrict__ rows, uint32_t* __restrict__ coefs) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;  // over tiles*3*2048 dwords
+    if (idx >= g.tiles * 3 * 2048) return;
+    uint32_t lane = idx & 63, p = (idx >> 6) & 31, tc = idx >> 11;
+    uint32_t tile = tc / 3, chan = tc - tile * 3;
+    uint32_t b = tile * 64 + lane;
+    uint32_t v = 0;
+    if (b < g.N) {
+        const int16_t* r = rows + ((size_t)chan * g.N + b) * 64;
+        v = ((uint32_t)(uint16_t)r[2 * p]) | ((uint32_t)(uint16_t)r[2 * p + 1] << 16);
+    }
+    coefs[idx] = v;
+}
+// unit_off (tile-local exclusive) + tile_bits -> per-unit bit counts, scan order
+__global__ void k_unit_bits(Geom g, const uint32_t* __restrict__ unit_off,
+                            const uint32_t* __restrict__ tile_bits, uint32_t* __restrict__ out) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * g.N) return;
+    uint32_t tile = idx / 192, j = idx - tile * 192;
+    uint32_t last = (tile + 1 == g.tiles) ? (3 * g.N - tile * 192) : 192;
+    uint32_t nxt = (j + 1 < last) ? unit_off[(size_t)tile * 192 + j + 1] : tile_bits[tile];
+    out[idx] = nxt - unit_off[(size_t)tile * 192 + j];
+}
+
+// ----------------------------------------------------------------------------
+// launchers (called from mi355_jpeg.cpp)
+// ----------------------------------------------------------------------------
+hipError_t launch_transform(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const double* qd,
+                            uint32_t* coefs, int mode, hipStream_t s) {
+    dim3 grid(g.tiles * 3, n_frames);
+    if (mode == 0)
+        hipLaunchKernelGGL((k_transform<0, false>), grid, dim3(64), 0, s, g, rgb, qd, coefs, nullptr);
+    else
+        hipLaunchKernelGGL((k_transform<1, false>), grid, dim3(64), 0, s, g, rgb, qd, coefs, nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_probe_samples(const Geom& g, const uint8_t* rgb, uint8_t* samples, hipStream_t s) {
+    dim3 grid(g.tiles * 3, 1);
+    hipLaunchKernelGGL((k_transform<1, true>), grid, dim3(64), 0, s, g, rgb, nullptr, nullptr, samples);
+    return hipGetLastError();
+}
+hipError_t launch_unit_sizes(const Geom& g, uint32_t n_frames, const uint32_t* coefs,
+                             const uint32_t* lut, uint32_t* unit_off, uint32_t* tile_bits,
+                             uint32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(k_unit_sizes, dim3(g.tiles, n_frames), dim3(192), 0, s, g, coefs, lut, unit_off,
+                       tile_bits, status);
+    return hipGetLastError();
+}
+hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, const uint32_t* tile_bits,
+                            uint64_t* tile_off, uint8_t* out, uint64_t out_stride,
+                            uint64_t* frame_bits, uint32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(k_tile_scan, dim3(n_frames), dim3(256), 0, s, g, tile_bits, tile_off, out,
+                       out_stride, frame_bits, status);
+    return hipGetLastError();
+}
+hipError_t launch_emit(const Geom& g, uint32_t n_frames, const uint32_t* coefs, const uint32_t* lut,
+                       const uint32_t* unit_off, const uint64_t* tile_off, uint8_t* out,
+                       uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,
+                       hipStream_t s) {
+    if (lds_words_limit > kEmitLdsWords) lds_words_limit = kEmitLdsWords;
+    hipLaunchKernelGGL(k_emit, dim3(g.tiles, n_frames), dim3(192), 0, s, g, coefs, lut, unit_off,
+                       tile_off, out, out_stride, status, lds_words_limit);
+    return hipGetLastError();
+}
+hipError_t launch_coefs_to_rows(const Geom& g, const uint32_t* coefs, int16_t* rows, hipStream_t s) {
+    hipLaunchKernelGGL(k_coefs_to_rows, dim3((3 * g.N + 3) / 4), dim3(256), 0, s, g, coefs, rows);
+    return hipGetLastError();
+}
+hipError_t launch_rows_to_coefs(const Geom& g, const int16_t* rows, uint32_t* coefs, hipStream_t s) {
+    uint32_t n = g.tiles * 3 * 2048;
+    hipLaunchKernelGGL(k_rows_to_coefs, dim3((n + 255) / 256), dim3(256), 0, s, g, rows, coefs);
+    return hipGetLastError();
+}
+hipError_t launch_unit_bits(const Geom& g, const uint32_t* unit_off, const uint32_t* tile_bits,
+                            uint32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_unit_bits, dim3((3 * g.N + 255) / 256), dim3(256), 0, s, g, unit_off,
+                       tile_bits, out);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

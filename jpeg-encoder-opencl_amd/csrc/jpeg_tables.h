@@ -1,0 +1,61 @@
+// Constant tables of the strict encode path, shared by host and device code of
+// the product library.  (The test oracle keeps its own copy on purpose.)
+//
+//  * kCosBits: cos((2a+1)*k*pi/16) exactly as glibc 2.35 rounds it for the
+//    reference's argument expression (reference src/utils.cpp:330).  The table is
+//    NOT sign-symmetric to the last bit, so it is shipped as data (SURVEY.md
+//    Appendix B) and never recomputed on the device.
+//  * scale constants alpha_u*alpha_v/4.0 (utils.cpp:318-319,336).
+//  * zig-zag order (utils.cpp:539-551 walks the 15 anti-diagonals).
+//  * ITU-T T.81 Annex K quantisation / Huffman specifications, which are what
+//    utils.hpp:42-62 and huffman.hpp spell out.
+#pragma once
+#include <stdint.h>
+
+namespace mi355 {
+
+#define MI355_COS_TABLE                                                                          \
+    {                                                                                            \
+        {0x1.0000000000000p+0, 0x1.f6297cff75cb0p-1, 0x1.d906bcf328d46p-1, 0x1.a9b66290ea1a3p-1, \
+         0x1.6a09e667f3bcdp-1, 0x1.1c73b39ae68c9p-1, 0x1.87de2a6aea964p-2, 0x1.8f8b83c69a60dp-3}, \
+        {0x1.0000000000000p+0, 0x1.a9b66290ea1a3p-1, 0x1.87de2a6aea964p-2, -0x1.8f8b83c69a608p-3, \
+         -0x1.6a09e667f3bccp-1, -0x1.f6297cff75cb0p-1, -0x1.d906bcf328d47p-1,                     \
+         -0x1.1c73b39ae68c8p-1},                                                                 \
+        {0x1.0000000000000p+0, 0x1.1c73b39ae68c9p-1, -0x1.87de2a6aea962p-2, -0x1.f6297cff75cb0p-1, \
+         -0x1.6a09e667f3bcep-1, 0x1.8f8b83c69a60cp-3, 0x1.d906bcf328d44p-1, 0x1.a9b66290ea1a5p-1}, \
+        {0x1.0000000000000p+0, 0x1.8f8b83c69a60dp-3, -0x1.d906bcf328d46p-1, -0x1.1c73b39ae68c8p-1, \
+         0x1.6a09e667f3bcbp-1, 0x1.a9b66290ea1a5p-1, -0x1.87de2a6aea965p-2, -0x1.f6297cff75cb2p-1}, \
+        {0x1.0000000000000p+0, -0x1.8f8b83c69a608p-3, -0x1.d906bcf328d47p-1, 0x1.1c73b39ae68c5p-1, \
+         0x1.6a09e667f3bcep-1, -0x1.a9b66290ea1a2p-1, -0x1.87de2a6aea971p-2, 0x1.f6297cff75cb0p-1}, \
+        {0x1.0000000000000p+0, -0x1.1c73b39ae68c6p-1, -0x1.87de2a6aea96dp-2, 0x1.f6297cff75cb0p-1, \
+         -0x1.6a09e667f3bc5p-1, -0x1.8f8b83c69a602p-3, 0x1.d906bcf328d46p-1,                      \
+         -0x1.a9b66290ea1a1p-1},                                                                 \
+        {0x1.0000000000000p+0, -0x1.a9b66290ea1a4p-1, 0x1.87de2a6aea967p-2, 0x1.8f8b83c69a61dp-3, \
+         -0x1.6a09e667f3bc9p-1, 0x1.f6297cff75cb2p-1, -0x1.d906bcf328d43p-1, 0x1.1c73b39ae68c2p-1}, \
+        {0x1.0000000000000p+0, -0x1.f6297cff75cb0p-1, 0x1.d906bcf328d44p-1, -0x1.a9b66290ea1a2p-1, \
+         0x1.6a09e667f3bc4p-1, -0x1.1c73b39ae68c2p-1, 0x1.87de2a6aea95fp-2,                       \
+         -0x1.8f8b83c69a616p-3},                                                                 \
+    }
+
+constexpr double kScale00 = 0x1.ffffffffffffep-4;  // u == 0 && v == 0
+constexpr double kScale0X = 0x1.6a09e667f3bccp-3;  // exactly one of u, v is 0
+constexpr double kScaleXX = 0x1p-2;                // neither
+
+// Natural index (v*8+u) of the k-th zig-zag coefficient.
+#define MI355_ZIGZAG_TABLE                                                                      \
+    {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,    \
+     41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,    \
+     30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63}
+
+// Colour conversion constants (utils.cpp:106-108), per output channel:
+// value = (uint8_t)(((k0*R + k1*G) + k2*B) + k3) in doubles, left to right.
+// "a - c*G" in the source equals "a + (-c)*G" bit for bit, and Y's missing
+// "+128" is written "+0.0" (Y >= +0, so the sum is unchanged).
+#define MI355_CSC_TABLE                              \
+    {                                                \
+        {0.299, 0.587, 0.114, 0.0},                  \
+        {-0.168736, -0.331264, 0.5, 128.0},          \
+        {0.5, -0.418688, -0.081312, 128.0},          \
+    }
+
+}  // namespace mi355

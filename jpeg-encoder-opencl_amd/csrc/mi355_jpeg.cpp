@@ -1,0 +1,621 @@
+// C ABI of the MI355X strict JPEG encode path (include/mi355_jpeg.h).
+//
+// Host-side runtime around the HIP kernels of jpeg_kernels.hip: context,
+// device workspace, table upload, launch sequencing, stage probes and the
+// build-defined JFIF framer.  There is no CPU compute path in this library: every
+// compute entry point needs a usable gfx950 device and fails loudly otherwise.
+#include "../../include/mi355_jpeg.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "jpeg_device.h"
+#include "jpeg_tables.h"
+
+using namespace mi355;
+
+namespace {
+
+// ---- Annex K tables (what utils.hpp:42-62 / huffman.hpp hold) --------------
+const uint8_t kQ50Lum[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
+                             14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+                             18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+                             49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uint8_t kQ50Chr[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+                             24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                             99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                             99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+const uint8_t kBitsDcL[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t kBitsDcC[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t kValDc[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t kBitsAcL[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uint8_t kValAcL[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07,
+    0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0,
+    0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28,
+    0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49,
+    0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69,
+    0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89,
+    0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7,
+    0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5,
+    0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8,
+    0xf9, 0xfa};
+const uint8_t kBitsAcC[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const uint8_t kValAcC[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71,
+    0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0,
+    0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26,
+    0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48,
+    0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68,
+    0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87,
+    0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5,
+    0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+    0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8,
+    0xf9, 0xfa};
+
+void canonical(const uint8_t bits[16], const uint8_t* val, mi355_huff_table* t) {
+    memset(t, 0, sizeof *t);
+    uint32_t code = 0;
+    int k = 0;
+    for (int l = 1; l <= 16; ++l) {
+        for (int i = 0; i < bits[l - 1]; ++i, ++k) {
+            t->code[val[k]] = code++;
+            t->len[val[k]] = (uint8_t)l;
+        }
+        code <<= 1;
+    }
+}
+
+// The reference's four code tables.  DC tables have 12 entries (sizes 0..11), AC
+// tables 16 runs x 11 sizes (0..10); everything else has no code.  huffman.hpp:92-98
+// spells AC-luma run 3 / sizes 4..10 with one extra leading '1' (17 bits): kept.
+void reference_huffman(int table, mi355_huff_table* t) {
+    switch (table) {
+        case 0: canonical(kBitsDcL, kValDc, t); break;
+        case 1: canonical(kBitsDcC, kValDc, t); break;
+        case 2: canonical(kBitsAcL, kValAcL, t); break;
+        default: canonical(kBitsAcC, kValAcC, t); break;
+    }
+    for (int rs = 0; rs < 256; ++rs) {
+        int run = rs >> 4, size = rs & 15;
+        bool has = table < 2 ? (run == 0 && size <= 11) : (size <= 10 && (size > 0 || run == 0 || run == 15));
+        if (!has) t->len[rs] = 0, t->code[rs] = 0;
+    }
+    if (table == 2)
+        for (int s = 4; s <= 10; ++s) {
+            int rs = (3 << 4) | s;
+            t->code[rs] |= 1u << t->len[rs];
+            t->len[rs] += 1;
+        }
+}
+
+struct Events {
+    hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool valid = false;
+};
+
+}  // namespace
+
+struct mi355_jpeg_ctx {
+    int device = 0;
+    uint32_t qlum[64], qchrom[64];
+    mi355_huff_table huff[4];
+    // device-resident tables
+    double* d_q = nullptr;       // [2][64] doubles, natural order
+    uint32_t* d_lut = nullptr;   // [4][256] code<<5|len
+    uint32_t* d_status = nullptr;
+    // workspace (grown on demand, never shrunk)
+    uint32_t* d_coefs = nullptr;
+    size_t coefs_cap = 0;  // dwords
+    uint32_t* d_unit_off = nullptr;
+    size_t unit_off_cap = 0;
+    uint32_t* d_tile_bits = nullptr;
+    uint64_t* d_tile_off = nullptr;
+    size_t tiles_cap = 0;  // entries of d_tile_bits; d_tile_off has tiles_cap + frames_cap
+    size_t tile_off_cap = 0;
+    // staging for the host-buffer entry points
+    uint8_t* d_in = nullptr;
+    size_t in_cap = 0;
+    uint8_t* d_out = nullptr;
+    size_t out_cap = 0;
+    uint64_t* d_bits = nullptr;
+    size_t bits_cap = 0;
+    int transform_mode = 0;
+    uint32_t emit_lds_words = 4096;
+    bool profiling = false;
+    Events ev;
+};
+
+namespace {
+
+inline int hip_err(hipError_t e) { return e == hipSuccess ? MI355_OK : MI355_E_HIP - (int)e; }
+#define HIP_TRY(x)                             \
+    do {                                       \
+        hipError_t _e = (x);                   \
+        if (_e != hipSuccess) return hip_err(_e); \
+    } while (0)
+
+template <typename T>
+int ensure(T*& p, size_t& cap, size_t need) {
+    if (need <= cap && p) return MI355_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    if (hipMalloc((void**)&p, need * sizeof(T)) != hipSuccess) return MI355_E_ALLOC;
+    cap = need;
+    return MI355_OK;
+}
+
+int upload_tables(mi355_jpeg_ctx* c) {
+    double q[128];
+    for (int i = 0; i < 64; ++i) {
+        q[i] = (double)c->qlum[i];
+        q[64 + i] = (double)c->qchrom[i];
+    }
+    uint32_t lut[4 * 256];
+    for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < 256; ++i)
+            lut[t * 256 + i] = c->huff[t].len[i] ? ((c->huff[t].code[i] << 5) | c->huff[t].len[i]) : 0u;
+    HIP_TRY(hipMemcpy(c->d_q, q, sizeof q, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    return MI355_OK;
+}
+
+int make_geom(uint32_t W, uint32_t H, uint32_t flags, const void* base, Geom* g) {
+    if (W == 0 || H == 0 || W > 65535u || H > 65535u) return MI355_E_ARG;
+    uint32_t W8 = (W + 7) / 8 * 8, H8 = (H + 7) / 8 * 8;
+    // the reference mirrors with `oldWidth - diff` in size_t (utils.cpp:215,226):
+    // a pad wider than the image underflows there (UB) -> refused here
+    if (W8 - W > W || H8 - H > H) return MI355_E_ARG;
+    g->W = W;
+    g->H = H;
+    g->W8 = W8;
+    g->H8 = H8;
+    g->nbx = W8 / 8;
+    g->N = (W8 / 8) * (H8 / 8);
+    g->tiles = (g->N + 63) / 64;
+    g->flags = flags;
+    g->frame_stride = (uint64_t)W * H * 3;
+    g->fast_rows = (W % 8 == 0) && (((uintptr_t)base & 7u) == 0);
+    return MI355_OK;
+}
+
+int ensure_workspace(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames) {
+    int e;
+    if ((e = ensure(c->d_coefs, c->coefs_cap, coef_dwords(g) * n_frames))) return e;
+    if ((e = ensure(c->d_unit_off, c->unit_off_cap, unit_off_words(g) * n_frames))) return e;
+    if ((e = ensure(c->d_tile_bits, c->tiles_cap, (size_t)g.tiles * n_frames))) return e;
+    if ((e = ensure(c->d_tile_off, c->tile_off_cap, ((size_t)g.tiles + 1) * n_frames))) return e;
+    return MI355_OK;
+}
+
+void record(mi355_jpeg_ctx* c, int i, hipStream_t s) {
+    if (!c->profiling) return;
+    if (!c->ev.e[0])
+        for (auto& e : c->ev.e) (void)hipEventCreate(&e);
+    (void)hipEventRecord(c->ev.e[i], s);
+    if (i == 4) c->ev.valid = true;
+}
+
+// entropy stages on coefficients already in the workspace
+int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_out, size_t out_stride,
+                uint64_t* d_bits, hipStream_t s) {
+    HIP_TRY(launch_unit_sizes(g, n_frames, c->d_coefs, c->d_lut, c->d_unit_off, c->d_tile_bits,
+                              c->d_status, s));
+    record(c, 2, s);
+    HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
+                             c->d_status, s));
+    record(c, 3, s);
+    HIP_TRY(launch_emit(g, n_frames, c->d_coefs, c->d_lut, c->d_unit_off, c->d_tile_off, d_out,
+                        out_stride, c->d_status, c->emit_lds_words, s));
+    record(c, 4, s);
+    return MI355_OK;
+}
+
+int status_to_error(uint32_t st) {
+    if (st & 1u) return MI355_E_CATEGORY;
+    if (st & 2u) return MI355_E_CAPACITY;
+    return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355_jpeg_abi_version(void) { return MI355_JPEG_ABI_VERSION; }
+
+const char* mi355_jpeg_strerror(int status) {
+    switch (status) {
+        case MI355_OK: return "ok";
+        case MI355_E_ARG: return "invalid argument";
+        case MI355_E_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+        case MI355_E_CAPACITY: return "output buffer too small";
+        case MI355_E_CATEGORY: return "coefficient size category outside the Huffman tables";
+        case MI355_E_ALLOC: return "allocation failed";
+        case MI355_E_TABLE: return "malformed table";
+        default: break;
+    }
+    if (status <= MI355_E_HIP) return hipGetErrorString((hipError_t)(MI355_E_HIP - status));
+    return "unknown error";
+}
+
+int mi355_jpeg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
+    if (!out) return MI355_E_ARG;
+    *out = nullptr;
+    int n = mi355_jpeg_device_count();
+    if (n <= 0 || device_id < 0 || device_id >= n) return MI355_E_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device_id));
+    mi355_jpeg_ctx* c = new (std::nothrow) mi355_jpeg_ctx();
+    if (!c) return MI355_E_ALLOC;
+    c->device = device_id;
+    for (int i = 0; i < 64; ++i) c->qlum[i] = kQ50Lum[i], c->qchrom[i] = kQ50Chr[i];
+    for (int t = 0; t < 4; ++t) reference_huffman(t, &c->huff[t]);
+    const char* m = getenv("MI355_JPEG_TRANSFORM_MODE");
+    if (m) c->transform_mode = atoi(m);
+    const char* l = getenv("MI355_JPEG_EMIT_LDS_WORDS");
+    if (l) c->emit_lds_words = (uint32_t)atoi(l);
+    int e = MI355_OK;
+    if (hipMalloc((void**)&c->d_q, 128 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&c->d_lut, 1024 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->d_status, sizeof(uint32_t)) != hipSuccess)
+        e = MI355_E_ALLOC;
+    if (!e) e = hip_err(hipMemset(c->d_status, 0, sizeof(uint32_t)));
+    if (!e) e = upload_tables(c);
+    if (e) {
+        mi355_jpeg_destroy(c);
+        return e;
+    }
+    *out = c;
+    return MI355_OK;
+}
+
+void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void* ptrs[] = {c->d_q, c->d_lut, c->d_status, c->d_coefs, c->d_unit_off, c->d_tile_bits,
+                    c->d_tile_off, c->d_in, c->d_out, c->d_bits};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& e : c->ev.e)
+        if (e) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int mi355_jpeg_set_quant(mi355_jpeg_ctx* c, const uint32_t qlum[64], const uint32_t qchrom[64]) {
+    if (!c || !qlum || !qchrom) return MI355_E_ARG;
+    for (int i = 0; i < 64; ++i)
+        if (qlum[i] < 1 || qlum[i] > 65535 || qchrom[i] < 1 || qchrom[i] > 65535) return MI355_E_TABLE;
+    memcpy(c->qlum, qlum, sizeof c->qlum);
+    memcpy(c->qchrom, qchrom, sizeof c->qchrom);
+    HIP_TRY(hipSetDevice(c->device));
+    return upload_tables(c);
+}
+
+int mi355_jpeg_set_quality(mi355_jpeg_ctx* c, int quality) {
+    if (!c || quality < 1 || quality > 100) return MI355_E_ARG;
+    uint32_t ql[64], qc[64];
+    int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
+    for (int i = 0; i < 64; ++i) {
+        long a = ((long)kQ50Lum[i] * scale + 50) / 100, b = ((long)kQ50Chr[i] * scale + 50) / 100;
+        ql[i] = (uint32_t)(a < 1 ? 1 : a > 255 ? 255 : a);
+        qc[i] = (uint32_t)(b < 1 ? 1 : b > 255 ? 255 : b);
+    }
+    return mi355_jpeg_set_quant(c, ql, qc);
+}
+
+int mi355_jpeg_set_huffman(mi355_jpeg_ctx* c, int table, const mi355_huff_table* t) {
+    if (!c || table < 0 || table > 3) return MI355_E_ARG;
+    mi355_huff_table nt;
+    if (t) {
+        nt = *t;
+        for (int i = 0; i < 256; ++i) {
+            if (nt.len[i] > 17) return MI355_E_TABLE;
+            if (nt.len[i] && (nt.code[i] >> nt.len[i])) return MI355_E_TABLE;
+        }
+        if (table >= 2 && (!nt.len[0x00] || !nt.len[0xF0])) return MI355_E_TABLE;  // EOB and ZRL are always needed
+    } else {
+        reference_huffman(table, &nt);
+    }
+    c->huff[table] = nt;
+    HIP_TRY(hipSetDevice(c->device));
+    return upload_tables(c);
+}
+
+int mi355_jpeg_get_quant(mi355_jpeg_ctx* c, uint32_t qlum[64], uint32_t qchrom[64]) {
+    if (!c || !qlum || !qchrom) return MI355_E_ARG;
+    memcpy(qlum, c->qlum, sizeof c->qlum);
+    memcpy(qchrom, c->qchrom, sizeof c->qchrom);
+    return MI355_OK;
+}
+
+int mi355_jpeg_get_huffman(mi355_jpeg_ctx* c, int table, mi355_huff_table* t) {
+    if (!c || !t || table < 0 || table > 3) return MI355_E_ARG;
+    *t = c->huff[table];
+    return MI355_OK;
+}
+
+void mi355_jpeg_padded_size(uint32_t W, uint32_t H, uint32_t* W8, uint32_t* H8) {
+    if (W8) *W8 = (W + 7) / 8 * 8;
+    if (H8) *H8 = (H + 7) / 8 * 8;
+}
+
+size_t mi355_jpeg_scan_bound(uint32_t W, uint32_t H) {
+    // per unit at most: DC 11+11 bits, 63 x (17+10) AC bits, EOB 4 -> 1727 bits
+    size_t units = (size_t)((W + 7) / 8) * ((H + 7) / 8) * 3;
+    return (units * 1727 + 7) / 8 + 8;
+}
+
+int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t W, uint32_t H,
+                                  uint32_t n_frames, uint32_t flags, void* d_out, size_t out_stride,
+                                  uint64_t* d_bits, void* stream) {
+    if (!c || !d_rgb || !d_out || !d_bits || n_frames == 0 || out_stride < 8 || (out_stride & 3) ||
+        ((uintptr_t)d_out & 3))
+        return MI355_E_ARG;
+    Geom g;
+    int e = make_geom(W, H, flags, d_rgb, &g);
+    if (e) return e;
+    if (n_frames > 65535u) return MI355_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((e = ensure_workspace(c, g, n_frames))) return e;
+    record(c, 0, s);
+    HIP_TRY(launch_transform(g, n_frames, (const uint8_t*)d_rgb, c->d_q, c->d_coefs, c->transform_mode, s));
+    record(c, 1, s);
+    return run_entropy(c, g, n_frames, (uint8_t*)d_out, out_stride, d_bits, s);
+}
+
+int mi355_jpeg_sync(mi355_jpeg_ctx* c, void* stream) {
+    if (!c) return MI355_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpy(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
+    if (st) HIP_TRY(hipMemset(c->d_status, 0, sizeof st));
+    return status_to_error(st);
+}
+
+int mi355_jpeg_encode_scan(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H,
+                           uint32_t n_frames, uint32_t flags, uint8_t* out, size_t out_stride,
+                           uint64_t* bits) {
+    if (!c || !rgb || !out || !bits || n_frames == 0) return MI355_E_ARG;
+    Geom g;
+    int e = make_geom(W, H, flags, nullptr, &g);
+    if (e) return e;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t in_bytes = (size_t)g.frame_stride * n_frames;
+    size_t dstride = (out_stride + 3) & ~(size_t)3;
+    if (dstride < 8) dstride = 8;
+    if ((e = ensure(c->d_in, c->in_cap, in_bytes))) return e;
+    if ((e = ensure(c->d_out, c->out_cap, dstride * n_frames))) return e;
+    if ((e = ensure(c->d_bits, c->bits_cap, (size_t)n_frames))) return e;
+    HIP_TRY(hipMemcpyAsync(c->d_in, rgb, in_bytes, hipMemcpyHostToDevice, nullptr));
+    // the device-side capacity check works on whole words; give it the caller's real limit
+    e = mi355_jpeg_encode_scan_device(c, c->d_in, W, H, n_frames, flags, c->d_out, dstride, c->d_bits, nullptr);
+    if (e) return e;
+    if ((e = mi355_jpeg_sync(c, nullptr))) return e;
+    HIP_TRY(hipMemcpy(bits, c->d_bits, sizeof(uint64_t) * n_frames, hipMemcpyDeviceToHost));
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        size_t nb = (size_t)((bits[f] + 7) / 8);
+        if (nb > out_stride) return MI355_E_CAPACITY;
+        HIP_TRY(hipMemcpy(out + (size_t)f * out_stride, c->d_out + (size_t)f * dstride, nb, hipMemcpyDeviceToHost));
+    }
+    return MI355_OK;
+}
+
+// ---- stage probes -----------------------------------------------------------
+
+int mi355_jpeg_probe_samples(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
+                             uint8_t* out) {
+    if (!c || !rgb || !out) return MI355_E_ARG;
+    Geom g;
+    int e = make_geom(W, H, flags, nullptr, &g);
+    if (e) return e;
+    HIP_TRY(hipSetDevice(c->device));
+    size_t ob = (size_t)g.W8 * g.H8 * 3;
+    if ((e = ensure(c->d_in, c->in_cap, (size_t)g.frame_stride))) return e;
+    if ((e = ensure(c->d_out, c->out_cap, ob))) return e;
+    HIP_TRY(hipMemcpy(c->d_in, rgb, g.frame_stride, hipMemcpyHostToDevice));
+    HIP_TRY(launch_probe_samples(g, c->d_in, c->d_out, nullptr));
+    HIP_TRY(hipMemcpy(out, c->d_out, ob, hipMemcpyDeviceToHost));
+    return MI355_OK;
+}
+
+static int transform_to_workspace(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H,
+                                  uint32_t flags, Geom* g) {
+    int e = make_geom(W, H, flags, nullptr, g);
+    if (e) return e;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((e = ensure(c->d_in, c->in_cap, (size_t)g->frame_stride))) return e;
+    if ((e = ensure_workspace(c, *g, 1))) return e;
+    HIP_TRY(hipMemcpy(c->d_in, rgb, g->frame_stride, hipMemcpyHostToDevice));
+    HIP_TRY(launch_transform(*g, 1, c->d_in, c->d_q, c->d_coefs, c->transform_mode, nullptr));
+    return MI355_OK;
+}
+
+int mi355_jpeg_probe_coefficients(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H,
+                                  uint32_t flags, int16_t* out) {
+    if (!c || !rgb || !out) return MI355_E_ARG;
+    Geom g;
+    int e = transform_to_workspace(c, rgb, W, H, flags, &g);
+    if (e) return e;
+    size_t ob = (size_t)g.N * 3 * 64 * sizeof(int16_t);
+    if ((e = ensure(c->d_out, c->out_cap, ob))) return e;
+    HIP_TRY(launch_coefs_to_rows(g, c->d_coefs, (int16_t*)c->d_out, nullptr));
+    HIP_TRY(hipMemcpy(out, c->d_out, ob, hipMemcpyDeviceToHost));
+    return MI355_OK;
+}
+
+int mi355_jpeg_probe_unit_bits(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
+                               uint32_t* out) {
+    if (!c || !rgb || !out) return MI355_E_ARG;
+    Geom g;
+    int e = transform_to_workspace(c, rgb, W, H, flags, &g);
+    if (e) return e;
+    size_t ob = (size_t)g.N * 3 * sizeof(uint32_t);
+    if ((e = ensure(c->d_out, c->out_cap, ob))) return e;
+    HIP_TRY(launch_unit_sizes(g, 1, c->d_coefs, c->d_lut, c->d_unit_off, c->d_tile_bits, c->d_status, nullptr));
+    HIP_TRY(launch_unit_bits(g, c->d_unit_off, c->d_tile_bits, (uint32_t*)c->d_out, nullptr));
+    if ((e = mi355_jpeg_sync(c, nullptr))) return e;
+    HIP_TRY(hipMemcpy(out, c->d_out, ob, hipMemcpyDeviceToHost));
+    return MI355_OK;
+}
+
+int mi355_jpeg_entropy_only(mi355_jpeg_ctx* c, const int16_t* zigzag, uint32_t n_blocks, uint8_t* out,
+                            size_t cap, uint64_t* bits) {
+    if (!c || !zigzag || !out || !bits || n_blocks == 0) return MI355_E_ARG;
+    Geom g;
+    memset(&g, 0, sizeof g);
+    g.N = n_blocks;
+    g.tiles = (n_blocks + 63) / 64;
+    HIP_TRY(hipSetDevice(c->device));
+    int e;
+    size_t ib = (size_t)n_blocks * 3 * 64 * sizeof(int16_t);
+    size_t dstride = (cap + 3) & ~(size_t)3;
+    if (dstride < 8) dstride = 8;
+    if ((e = ensure(c->d_in, c->in_cap, ib))) return e;
+    if ((e = ensure(c->d_out, c->out_cap, dstride))) return e;
+    if ((e = ensure(c->d_bits, c->bits_cap, (size_t)1))) return e;
+    if ((e = ensure_workspace(c, g, 1))) return e;
+    HIP_TRY(hipMemcpy(c->d_in, zigzag, ib, hipMemcpyHostToDevice));
+    HIP_TRY(launch_rows_to_coefs(g, (const int16_t*)c->d_in, c->d_coefs, nullptr));
+    if ((e = run_entropy(c, g, 1, c->d_out, dstride, c->d_bits, nullptr))) return e;
+    if ((e = mi355_jpeg_sync(c, nullptr))) return e;
+    HIP_TRY(hipMemcpy(bits, c->d_bits, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    size_t nb = (size_t)((*bits + 7) / 8);
+    if (nb > cap) return MI355_E_CAPACITY;
+    HIP_TRY(hipMemcpy(out, c->d_out, nb, hipMemcpyDeviceToHost));
+    return MI355_OK;
+}
+
+// ---- JFIF framing (build-defined) ----------------------
+
+namespace {
+struct Writer {
+    uint8_t* p;
+    size_t n, cap;
+    void b(unsigned v) {
+        if (n < cap) p[n] = (uint8_t)v;
+        ++n;
+    }
+    void w(unsigned v) {
+        b(v >> 8);
+        b(v & 255);
+    }
+};
+// BITS/HUFFVAL of a table, by sorting its codes by (length, code).  Codes longer
+// than 16 bits (the reference's seven 17-bit entries) cannot be expressed in a DHT
+// segment: they are listed at 16 bits, so strict-mode files are parity artefacts,
+// not guaranteed-decodable pictures.
+void dht_segment(Writer& w, int cls_id, const mi355_huff_table& t) {
+    uint8_t bits[16] = {0};
+    std::vector<uint8_t> vals;
+    for (int l = 1; l <= 16; ++l) {
+        std::vector<std::pair<uint32_t, int>> at;
+        for (int i = 0; i < 256; ++i) {
+            int li = t.len[i];
+            uint32_t ci = t.code[i];
+            if (li == 17) li = 16, ci &= 0xFFFFu;  // listed without the extra leading '1'
+            if (li == l) at.push_back({ci, i});
+        }
+        for (size_t a = 0; a < at.size(); ++a)
+            for (size_t b2 = a + 1; b2 < at.size(); ++b2)
+                if (at[b2].first < at[a].first) std::swap(at[a], at[b2]);
+        for (auto& pr : at) {
+            bits[l - 1]++;
+            vals.push_back((uint8_t)pr.second);
+        }
+    }
+    w.w(0xFFC4);
+    w.w((unsigned)(2 + 1 + 16 + vals.size()));
+    w.b(cls_id);
+    for (int i = 0; i < 16; ++i) w.b(bits[i]);
+    for (uint8_t v : vals) w.b(v);
+}
+}  // namespace
+
+int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
+                           uint8_t* out, size_t cap, size_t* out_len) {
+    if (!c || !rgb || !out || !out_len) return MI355_E_ARG;
+    size_t bound = mi355_jpeg_scan_bound(W, H);
+    std::vector<uint8_t> scan;
+    uint64_t nbits = 0;
+    // try a modest buffer first (8 bits/px), fall back to the worst-case bound
+    size_t guess = (size_t)W * H + 4096;
+    if (guess > bound) guess = bound;
+    scan.resize(guess);
+    int e = mi355_jpeg_encode_scan(c, rgb, W, H, 1, flags, scan.data(), scan.size(), &nbits);
+    if (e == MI355_E_CAPACITY) {
+        scan.resize(bound);
+        e = mi355_jpeg_encode_scan(c, rgb, W, H, 1, flags, scan.data(), scan.size(), &nbits);
+    }
+    if (e) return e;
+    static const uint8_t zz[64] = MI355_ZIGZAG_TABLE;
+    Writer w{out, 0, cap};
+    w.w(0xFFD8);
+    w.w(0xFFE0), w.w(16);
+    w.b('J'), w.b('F'), w.b('I'), w.b('F'), w.b(0);
+    w.w(0x0101), w.b(0), w.w(1), w.w(1), w.b(0), w.b(0);
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t* q = t ? c->qchrom : c->qlum;
+        w.w(0xFFDB), w.w(67), w.b(t);
+        for (int k = 0; k < 64; ++k) w.b(q[zz[k]] > 255 ? 255 : q[zz[k]]);
+    }
+    w.w(0xFFC0), w.w(17), w.b(8), w.w(H), w.w(W), w.b(3);
+    w.b(1), w.b(0x11), w.b(0);
+    w.b(2), w.b(0x11), w.b(1);
+    w.b(3), w.b(0x11), w.b(1);
+    dht_segment(w, 0x00, c->huff[0]);
+    dht_segment(w, 0x10, c->huff[2]);
+    dht_segment(w, 0x01, c->huff[1]);
+    dht_segment(w, 0x11, c->huff[3]);
+    w.w(0xFFDA), w.w(12), w.b(3);
+    w.b(1), w.b(0x00), w.b(2), w.b(0x11), w.b(3), w.b(0x11);
+    w.b(0), w.b(63), w.b(0);
+    size_t nb = (size_t)((nbits + 7) / 8);
+    for (size_t i = 0; i < nb; ++i) {
+        unsigned b = scan[i];
+        if (i == nb - 1 && (nbits & 7)) b |= 0xFFu >> (nbits & 7);  // pad with 1s
+        w.b(b);
+        if (b == 0xFF) w.b(0);
+    }
+    w.w(0xFFD9);
+    *out_len = w.n;
+    return w.n > cap ? MI355_E_CAPACITY : MI355_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------
+
+int mi355_jpeg_set_profiling(mi355_jpeg_ctx* c, int on) {
+    if (!c) return MI355_E_ARG;
+    c->profiling = on != 0;
+    c->ev.valid = false;
+    return MI355_OK;
+}
+
+int mi355_jpeg_last_timings(mi355_jpeg_ctx* c, mi355_jpeg_timings* t) {
+    if (!c || !t) return MI355_E_ARG;
+    memset(t, 0, sizeof *t);
+    if (!c->ev.valid) return MI355_E_ARG;
+    HIP_TRY(hipEventSynchronize(c->ev.e[4]));
+    HIP_TRY(hipEventElapsedTime(&t->transform_ms, c->ev.e[0], c->ev.e[1]));
+    HIP_TRY(hipEventElapsedTime(&t->size_ms, c->ev.e[1], c->ev.e[2]));
+    HIP_TRY(hipEventElapsedTime(&t->scan_ms, c->ev.e[2], c->ev.e[3]));
+    HIP_TRY(hipEventElapsedTime(&t->emit_ms, c->ev.e[3], c->ev.e[4]));
+    HIP_TRY(hipEventElapsedTime(&t->total_ms, c->ev.e[0], c->ev.e[4]));
+    return MI355_OK;
+}
+
+}  // extern "C"
