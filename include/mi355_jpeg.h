@@ -150,11 +150,16 @@ int mi355_jpeg_entropy_only(mi355_jpeg_ctx *ctx, const int16_t *zigzag, uint32_t
                             uint8_t *out, size_t cap, uint64_t *bits);
 
 /* ---- measurement ------------------------------------------------------- */
-/* Enable per-stage HIP-event timing on the next encode calls (adds events on the
- * stream; off by default). */
-int mi355_jpeg_set_profiling(mi355_jpeg_ctx *ctx, int on);
+/* mode 0: off (default).  mode 1: HIP events around every stage of each encode
+ * call, recorded on the call's stream.  mode 2: events around the transform
+ * kernel only (two records per call; what bench.py keeps on during the timed
+ * region).  Enabling resets the accumulated sums. */
+int mi355_jpeg_set_profiling(mi355_jpeg_ctx *ctx, int mode);
 /* Stage times of the last *_device or host encode call (waits for its events). */
 int mi355_jpeg_last_timings(mi355_jpeg_ctx *ctx, mi355_jpeg_timings *t);
+/* Sums over all encode calls since profiling was enabled (waits for their
+ * events); *calls receives the number of calls summed. */
+int mi355_jpeg_profile_summary(mi355_jpeg_ctx *ctx, mi355_jpeg_timings *sum, uint32_t *calls);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,7 @@ ABI_SYMBOLS = [
     "mi355_jpeg_encode_scan", "mi355_jpeg_encode_scan_device", "mi355_jpeg_sync", "mi355_jpeg_encode_jfif",
     "mi355_jpeg_probe_samples", "mi355_jpeg_probe_coefficients", "mi355_jpeg_probe_unit_bits",
     "mi355_jpeg_entropy_only", "mi355_jpeg_set_profiling", "mi355_jpeg_last_timings",
+    "mi355_jpeg_profile_summary",
 ]
 
 _lib = None
@@ -99,10 +100,9 @@ def lib():
         L.mi355_jpeg_entropy_only.argtypes = [vp, vp, u32, vp, sz, u64p]
         L.mi355_jpeg_set_profiling.argtypes = [vp, C.c_int]
         L.mi355_jpeg_last_timings.argtypes = [vp, C.POINTER(Timings)]
-        for name in ABI_SYMBOLS:
-            f = getattr(L, name)
-            if f.restype is C.c_int and name not in ("mi355_jpeg_abi_version", "mi355_jpeg_device_count"):
-                pass
+        L.mi355_jpeg_profile_summary.argtypes = [vp, C.POINTER(Timings), C.POINTER(u32)]
+        for name in ABI_SYMBOLS:  # fail at load time, not at first use, if a symbol is missing
+            getattr(L, name)
         _lib = L
     return _lib
 
@@ -238,8 +238,15 @@ class Encoder:
         return out[:(bits.value + 7) // 8].copy(), bits.value
 
     # ---- measurement
-    def set_profiling(self, on=True):
-        _check(lib().mi355_jpeg_set_profiling(self._h, int(on)))
+    def set_profiling(self, mode=1):
+        """0 off, 1 events around every stage, 2 around the transform kernel only."""
+        _check(lib().mi355_jpeg_set_profiling(self._h, int(mode)))
+
+    def profile_summary(self):
+        """(sums in ms over the profiled calls, number of calls)."""
+        t, n = Timings(), C.c_uint32()
+        _check(lib().mi355_jpeg_profile_summary(self._h, C.byref(t), C.byref(n)))
+        return {k: getattr(t, k) for k, _ in Timings._fields_}, n.value
 
     def last_timings(self):
         t = Timings()

@@ -96,9 +96,10 @@ void reference_huffman(int table, mi355_huff_table* t) {
         }
 }
 
-struct Events {
+// One set of stage-boundary events per profiled encode call (slots 0..4:
+// start, after transform, after sizes, after scan, after emit).
+struct EventSet {
     hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool valid = false;
 };
 
 }  // namespace
@@ -129,8 +130,10 @@ struct mi355_jpeg_ctx {
     size_t bits_cap = 0;
     int transform_mode = 0;
     uint32_t emit_lds_words = 4096;
-    bool profiling = false;
-    Events ev;
+    int profiling = 0;              // 0 off, 1 all stages, 2 transform only
+    std::vector<EventSet> ev_pool;  // grown on demand, reused after a reset
+    size_t ev_used = 0;             // sets recorded since profiling was enabled
+    bool ev_open = false;           // between slot 0 and the last slot of one encode call
 };
 
 namespace {
@@ -196,12 +199,46 @@ int ensure_workspace(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames) {
     return MI355_OK;
 }
 
+constexpr size_t kMaxEventSets = 1u << 16;
+
+// slot 0 opens a new event set for this call
 void record(mi355_jpeg_ctx* c, int i, hipStream_t s) {
     if (!c->profiling) return;
-    if (!c->ev.e[0])
-        for (auto& e : c->ev.e) (void)hipEventCreate(&e);
-    (void)hipEventRecord(c->ev.e[i], s);
-    if (i == 4) c->ev.valid = true;
+    if (c->profiling == 2 && i > 1) return;
+    if (i == 0) {
+        if (c->ev_used >= kMaxEventSets) c->ev_used = 0;  // wrap: keep the most recent calls
+        if (c->ev_used == c->ev_pool.size()) c->ev_pool.emplace_back();
+        ++c->ev_used;
+        c->ev_open = true;
+    }
+    if (!c->ev_open) return;  // stage probes / entropy-only calls are not profiled
+    if (i == (c->profiling == 2 ? 1 : 4)) c->ev_open = false;
+    EventSet& es = c->ev_pool[c->ev_used - 1];
+    if (!es.e[i] && hipEventCreate(&es.e[i]) != hipSuccess) return;
+    (void)hipEventRecord(es.e[i], s);
+}
+
+int elapsed(const EventSet& es, int a, int b, float* ms) {
+    *ms = 0.f;
+    if (!es.e[a] || !es.e[b]) return MI355_OK;
+    hipError_t e = hipEventSynchronize(es.e[b]);
+    if (e != hipSuccess) return MI355_E_HIP - (int)e;
+    e = hipEventElapsedTime(ms, es.e[a], es.e[b]);
+    return e == hipSuccess ? MI355_OK : MI355_E_HIP - (int)e;
+}
+
+int timings_of(mi355_jpeg_ctx* c, const EventSet& es, mi355_jpeg_timings* t) {
+    int e;
+    memset(t, 0, sizeof *t);
+    if ((e = elapsed(es, 0, 1, &t->transform_ms))) return e;
+    if (c->profiling == 2) {
+        t->total_ms = t->transform_ms;
+        return MI355_OK;
+    }
+    if ((e = elapsed(es, 1, 2, &t->size_ms))) return e;
+    if ((e = elapsed(es, 2, 3, &t->scan_ms))) return e;
+    if ((e = elapsed(es, 3, 4, &t->emit_ms))) return e;
+    return elapsed(es, 0, 4, &t->total_ms);
 }
 
 // entropy stages on coefficients already in the workspace
@@ -289,8 +326,9 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
                     c->d_tile_off, c->d_in, c->d_out, c->d_bits};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    for (auto& e : c->ev.e)
-        if (e) (void)hipEventDestroy(e);
+    for (auto& es : c->ev_pool)
+        for (auto& e : es.e)
+            if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -598,23 +636,39 @@ int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, ui
 
 // ---- measurement ---------------------------------------------------------------
 
-int mi355_jpeg_set_profiling(mi355_jpeg_ctx* c, int on) {
-    if (!c) return MI355_E_ARG;
-    c->profiling = on != 0;
-    c->ev.valid = false;
+int mi355_jpeg_set_profiling(mi355_jpeg_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return MI355_E_ARG;
+    // stage probes and the entropy-only entry point do not open event sets: drop
+    // half-recorded state by starting over
+    c->profiling = mode;
+    c->ev_used = 0;
+    c->ev_open = false;
     return MI355_OK;
 }
 
 int mi355_jpeg_last_timings(mi355_jpeg_ctx* c, mi355_jpeg_timings* t) {
     if (!c || !t) return MI355_E_ARG;
     memset(t, 0, sizeof *t);
-    if (!c->ev.valid) return MI355_E_ARG;
-    HIP_TRY(hipEventSynchronize(c->ev.e[4]));
-    HIP_TRY(hipEventElapsedTime(&t->transform_ms, c->ev.e[0], c->ev.e[1]));
-    HIP_TRY(hipEventElapsedTime(&t->size_ms, c->ev.e[1], c->ev.e[2]));
-    HIP_TRY(hipEventElapsedTime(&t->scan_ms, c->ev.e[2], c->ev.e[3]));
-    HIP_TRY(hipEventElapsedTime(&t->emit_ms, c->ev.e[3], c->ev.e[4]));
-    HIP_TRY(hipEventElapsedTime(&t->total_ms, c->ev.e[0], c->ev.e[4]));
+    if (!c->profiling || c->ev_used == 0) return MI355_E_ARG;
+    return timings_of(c, c->ev_pool[c->ev_used - 1], t);
+}
+
+int mi355_jpeg_profile_summary(mi355_jpeg_ctx* c, mi355_jpeg_timings* sum, uint32_t* calls) {
+    if (!c || !sum || !calls) return MI355_E_ARG;
+    memset(sum, 0, sizeof *sum);
+    *calls = 0;
+    if (!c->profiling) return MI355_E_ARG;
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        mi355_jpeg_timings t;
+        int e = timings_of(c, c->ev_pool[i], &t);
+        if (e) return e;
+        acc[0] += t.transform_ms, acc[1] += t.size_ms, acc[2] += t.scan_ms, acc[3] += t.emit_ms,
+            acc[4] += t.total_ms;
+    }
+    sum->transform_ms = (float)acc[0], sum->size_ms = (float)acc[1], sum->scan_ms = (float)acc[2];
+    sum->emit_ms = (float)acc[3], sum->total_ms = (float)acc[4];
+    *calls = (uint32_t)c->ev_used;
     return MI355_OK;
 }
 

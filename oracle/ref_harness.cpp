@@ -191,6 +191,16 @@ uint64_t ref_nbits(void *h) { return static_cast<RefRun *>(h)->bits.size(); }
 const char *ref_bits(void *h) { return static_cast<RefRun *>(h)->bits.data(); }
 const double *ref_stage_us(void *h) { return static_cast<RefRun *>(h)->us; }
 
+// performCSC alone (utils.cpp:92-110), in place on npix interleaved pixels: used
+// for the exhaustive 2^24 colour-conversion check.
+void ref_csc_only(uint8_t *px, size_t npix) {
+    ppm_t img;
+    img.width = npix;
+    img.height = 1;
+    img.data = (rgb_pixel_t *)px;
+    performCSC(&img);
+}
+
 // The reference's constant tables, for pinning the restatement's tables.
 void ref_quant_tables(uint32_t *qlum, uint32_t *qchrom) {
     for (int i = 0; i < 64; ++i) {

@@ -99,6 +99,7 @@ def ref():
             f = getattr(L, name)
             f.restype = rt
             f.argtypes = [C.c_void_p]
+        L.ref_csc_only.argtypes = [C.c_void_p, C.c_size_t]
         L.ref_quant_tables.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_huff_code.restype = C.c_int
         L.ref_huff_code.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p]

@@ -1,0 +1,247 @@
+"""CPU suite (-m "not gpu"): the oracle against the golden vectors generated from the
+real reference build, against the reference build itself where present, plus host
+logic and the C-ABI surface (no compute calls without a GPU)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import GOLD, ROOT, case_input, load_cases
+
+SMALL = [c for c in load_cases() if not c.get("big")]
+
+
+def ascii_sha(bits, n_bits):
+    a = (np.unpackbits(bits)[:n_bits] + ord("0")).astype(np.uint8)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("case", SMALL, ids=[c["name"] for c in SMALL])
+def test_oracle_matches_golden(case):
+    rgb = case_input(case)
+    ql, qc = ol.quant_tables(case["quality"])
+    keep = ol.KEEP_ZIGZAG | ol.KEEP_U8_STAGES | ol.KEEP_DCT | ol.KEEP_UNIT_BITS
+    o = ol.oracle_encode(rgb, ql, qc, case["cds_on"], keep)
+    assert o.n_bits == case["n_bits"]
+    assert ascii_sha(o.bits, o.n_bits) == case["sha256_ascii_bits"]
+    assert hashlib.sha256(o.bits.tobytes()).hexdigest() == case["sha256_packed_bits"]
+    assert hashlib.sha256(o.zigzag.astype("<i4").tobytes()).hexdigest() == case["sha256_zigzag_i32"]
+    assert int(o.unit_bits.sum()) == o.n_bits
+    if "sha256_csc" in case:
+        assert hashlib.sha256(o.csc.tobytes()).hexdigest() == case["sha256_csc"]
+        assert hashlib.sha256(o.cds.tobytes()).hexdigest() == case["sha256_cds"]
+        assert hashlib.sha256(o.padded.tobytes()).hexdigest() == case["sha256_padded"]
+        assert hashlib.sha256(o.dct.astype("<f8").tobytes()).hexdigest() == case["sha256_dct_f64"]
+
+
+def test_fruit_scan_bits_file():
+    """The committed scan bits of the reference's sample image (307 829
+    bits, sha256 f1908bb1...)."""
+    case = [c for c in SMALL if c["name"] == "fruit_q50_cds"][0]
+    assert case["n_bits"] == 307829
+    assert case["sha256_ascii_bits"] == "f1908bb11a185e4c649f0ae0084fd82541ea0bdc91efcd1c9f366bc0fbe4bfe5"
+    gold = np.fromfile(os.path.join(GOLD, "fruit_q50_cds.scanbits"), np.uint8)
+    o = ol.oracle_encode(case_input(case), keep=ol.KEEP_ZIGZAG)
+    assert np.array_equal(o.bits, gold)
+    zz = np.fromfile(os.path.join(GOLD, "fruit_q50_cds.zigzag_i16"), "<i2").reshape(-1, 64)
+    assert np.array_equal(o.zigzag, zz.astype(np.int32))
+    first = "".join(str(b) for b in np.unpackbits(o.bits)[:64])
+    assert first == case["first64"]
+
+
+def test_tables_match_reference_dump():
+    with open(os.path.join(GOLD, "tables.json")) as f:
+        t = json.load(f)
+    L = ol.oracle()
+    for a in range(8):
+        for k in range(8):
+            assert float.hex(L.orc_cos(a, k)) == t["cos"][a][k]
+    assert float.hex(L.orc_scale(0, 0)) == t["scale"]["00"]
+    assert float.hex(L.orc_scale(0, 3)) == t["scale"]["0x"]
+    assert float.hex(L.orc_scale(2, 0)) == t["scale"]["x0"]
+    assert float.hex(L.orc_scale(5, 6)) == t["scale"]["xx"]
+    ql, qc = ol.quant_tables(50)
+    assert ql.tolist() == t["quant_lum"] and qc.tolist() == t["quant_chrom"]
+    n17 = 0
+    for ti, name in enumerate(["dc_luma", "dc_chroma", "ac_luma", "ac_chroma"]):
+        for run, row in enumerate(t["huffman"][name]):
+            for size, s in enumerate(row):
+                code = C.c_uint32()
+                n = L.orc_huff_code(ti, run, size, C.byref(code))
+                if s is None:
+                    assert n == -1
+                else:
+                    assert n == len(s) and format(code.value, "0%db" % n) == s
+                    n17 += n == 17
+    assert n17 == 7  # huffman.hpp:92-98
+    # out-of-table categories are errors, not out-of-bounds reads
+    assert L.orc_huff_code(0, 0, 12, None) == -1
+    assert L.orc_huff_code(2, 0, 11, None) == -1
+    assert L.orc_huff_code(3, 16, 1, None) == -1
+
+
+def test_zigzag_is_the_standard_order():
+    zz = np.zeros(64, np.uint8)
+    ol.oracle().orc_zigzag_order(zz.ctypes.data)
+    std = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20,
+           13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52,
+           45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+    assert zz.tolist() == std
+
+
+def test_exhaustive_colour_conversion():
+    """All 2^24 RGB triples through the restated CSC vs the reference's output hash."""
+    with open(os.path.join(GOLD, "tables.json")) as f:
+        want = json.load(f)["csc_exhaustive_sha256"]
+    i = np.arange(1 << 24, dtype=np.uint32)
+    px = np.stack([(i >> 16) & 255, (i >> 8) & 255, i & 255], -1).astype(np.uint8)
+    ol.oracle().orc_csc(px.ctypes.data, 1 << 24)
+    assert hashlib.sha256(px.tobytes()).hexdigest() == want
+    assert px[-1].tolist()[0] == 255 and px[:, 0].min() == 0
+
+
+def test_in_place_transform_is_not_a_dct():
+    """Quirk Q5: the in-place chain differs from a true DCT-II (and the oracle follows
+    the chain).  Also pins the restatement's single-block function."""
+    rng = np.random.default_rng(3)
+    P = rng.integers(-128, 128, 64).astype(np.float64)
+    Q = P.copy()
+    ol.oracle().orc_dct_block(Q.ctypes.data)
+    x = np.arange(8)
+    Cm = np.cos((2 * x[:, None] + 1) * x[None, :] * np.pi / 16)
+    al = np.where(x == 0, 1 / np.sqrt(2), 1.0)
+    true = 0.25 * al[:, None] * al[None, :] * (Cm.T @ P.reshape(8, 8) @ Cm)  # [v][u]
+    assert abs(Q[0] - true[0, 0]) < 1e-9          # the first output is still the true DC
+    assert np.abs(Q.reshape(8, 8) - true).max() > 1.0  # later ones are not
+
+
+def test_rle_quirks_single_unit():
+    """Always-EOB (Q8), ZRL on every 16th zero, 17-bit codes (Q11)."""
+    L = ol.oracle()
+
+    def bits_of(zz, chroma=False, diff=None):
+        z = np.zeros((3, 64), np.int32)
+        z[1 if chroma else 0] = zz
+        out, nb, n = C.POINTER(C.c_uint8)(), C.c_size_t(), C.c_uint64()
+        ub = np.zeros(3, np.uint32)
+        assert L.orc_entropy(z.ctypes.data, 1, C.byref(out), C.byref(nb), C.byref(n), ub.ctypes.data) == 0
+        return int(ub[1 if chroma else 0])
+
+    zero = np.zeros(64, np.int32)
+    assert bits_of(zero) == 2 + 4            # DC size 0 ("00") + EOB ("1010")
+    assert bits_of(zero, chroma=True) == 2 + 2
+    z = zero.copy(); z[63] = 1               # 62 zeros -> 3 ZRL, then (14,1), then EOB anyway
+    assert bits_of(z) == 2 + 3 * 11 + (16 + 1) + 4
+    z = zero.copy(); z[4] = 9                # run 3, size 4 -> the 17-bit code
+    assert bits_of(z) == 2 + (17 + 4) + 4
+    z = zero.copy(); z[0] = -3               # DC only: size 2 code "011" + 2 bits
+    assert bits_of(z) == 3 + 2 + 4
+
+
+def test_category_out_of_range_is_an_error():
+    z = np.zeros((3, 64), np.int32)
+    z[0, 5] = 1024  # AC size 11: no code in the reference tables
+    out, nb, n = C.POINTER(C.c_uint8)(), C.c_size_t(), C.c_uint64()
+    assert ol.oracle().orc_entropy(z.ctypes.data, 1, C.byref(out), C.byref(nb), C.byref(n), None) == -3
+    z[0, 5] = 1023
+    assert ol.oracle().orc_entropy(z.ctypes.data, 1, C.byref(out), C.byref(nb), C.byref(n), None) == 0
+
+
+def test_refuses_pad_wider_than_image():
+    with pytest.raises(RuntimeError):
+        ol.oracle_encode(np.zeros((8, 3, 3), np.uint8))  # W=3 -> pad 5 > 3: reference UB
+    ol.oracle_encode(np.zeros((4, 4, 3), np.uint8))        # pad 4 == W: fine
+
+
+@pytest.mark.skipif(not ol.ref_available(), reason="real reference build only exists in the build container")
+def test_oracle_vs_real_reference_random():
+    rng = np.random.default_rng(11)
+    keep = ol.KEEP_ZIGZAG | ol.KEEP_U8_STAGES | ol.KEEP_DCT
+    for it in range(24):
+        W, H = int(rng.integers(4, 90)), int(rng.integers(4, 90))
+        if (W + 7) // 8 * 8 - W > W or (H + 7) // 8 * 8 - H > H:
+            continue
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        if it % 3 == 1:
+            rgb = (rgb // 64 * 64).astype(np.uint8)
+        ql, qc = ol.quant_tables([50, 75, 90, 100, 10][it % 5])
+        cds = it % 4 != 3
+        r = ol.ref_encode(rgb, ql, qc, cds, keep)
+        o = ol.oracle_encode(rgb, ql, qc, cds, keep)
+        assert r.n_bits == o.n_bits
+        for k in ("csc", "cds", "padded", "zigzag", "bits"):
+            assert np.array_equal(getattr(r, k), getattr(o, k)), (k, W, H)
+        assert np.array_equal(r.dct.view(np.uint64), o.dct.view(np.uint64))
+
+
+def test_jfif_framing_structure():
+    case = [c for c in SMALL if c["name"] == "fruit_q50_cds"][0]
+    rgb = case_input(case)
+    o = ol.oracle_encode(rgb)
+    ql, qc = ol.quant_tables(50)
+    f = ol.jfif_frame(o.bits, o.n_bits, rgb.shape[1], rgb.shape[0], ql, qc)
+    assert f[:2] == b"\xff\xd8" and f[-2:] == b"\xff\xd9"
+    assert f[2:4] == b"\xff\xe0" and f[6:11] == b"JFIF\0"
+    sof = f.index(b"\xff\xc0")
+    assert f[sof + 5:sof + 9] == bytes([0, 254, 0, 253])  # H, W = original (unpadded) size
+    sos = f.index(b"\xff\xda")
+    body = f[sos + 14:-2]
+    # stuffing: every 0xFF in the entropy segment is followed by 0x00
+    idx = [i for i in range(len(body)) if body[i] == 0xFF]
+    assert all(body[i + 1] == 0 for i in idx)
+    unstuffed = body.replace(b"\xff\x00", b"\xff")
+    assert len(unstuffed) == (o.n_bits + 7) // 8
+    assert unstuffed[:-1] == o.bits.tobytes()[:-1]
+
+
+# ---------------------------------------------------------------- product: host side only
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "mi355_jpeg.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355_jpeg_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_abi_exports_every_declared_symbol(jpeg):
+    syms = header_symbols()
+    assert len(syms) >= 20
+    L = jpeg.lib()
+    for s in syms:
+        assert hasattr(L, s), "libmi355jpeg.so does not export " + s
+    assert sorted(jpeg.ABI_SYMBOLS) == syms
+    assert L.mi355_jpeg_abi_version() == 1
+
+
+def test_host_helpers_without_a_gpu(jpeg):
+    L = jpeg.lib()
+    w8, h8 = C.c_uint32(), C.c_uint32()
+    L.mi355_jpeg_padded_size(253, 254, C.byref(w8), C.byref(h8))
+    assert (w8.value, h8.value) == (256, 256)
+    L.mi355_jpeg_padded_size(3840, 2160, C.byref(w8), C.byref(h8))
+    assert (w8.value, h8.value) == (3840, 2160)
+    assert jpeg.scan_bound(8, 8) >= (3 * 1727 + 7) // 8
+    assert b"no usable HIP device" in L.mi355_jpeg_strerror(jpeg.E_NO_DEVICE)
+    assert L.mi355_jpeg_strerror(0) == b"ok"
+
+
+def test_no_cpu_fallback_when_no_device(jpeg):
+    if jpeg.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(jpeg.JpegError) as ei:
+        jpeg.Encoder(0)
+    assert ei.value.status == jpeg.E_NO_DEVICE
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product sources must not include, link or import anything under oracle/."""
+    pkg = os.path.join(ROOT, "jpeg-encoder-opencl_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                text = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "oracle_lib" not in text and "jpeg_oracle" not in text and "liboracle" not in text, fn

@@ -86,9 +86,14 @@ def main():
     ql = np.zeros(64, np.uint32)
     qc = np.zeros(64, np.uint32)
     L.ref_quant_tables(ql.ctypes.data, qc.ctypes.data)
+    # exhaustive colour conversion: pixel index i = r<<16 | g<<8 | b through performCSC
+    i = np.arange(1 << 24, dtype=np.uint32)
+    allrgb = np.stack([(i >> 16) & 255, (i >> 8) & 255, i & 255], -1).astype(np.uint8)
+    L.ref_csc_only(allrgb.ctypes.data, 1 << 24)
+    csc_sha = hashlib.sha256(allrgb.tobytes()).hexdigest()
     with open(os.path.join(GOLD, "tables.json"), "w") as f:
         json.dump({"cos": cos, "scale": scale, "huffman": huff, "quant_lum": ql.tolist(),
-                   "quant_chrom": qc.tolist()}, f, indent=1)
+                   "quant_chrom": qc.tolist(), "csc_exhaustive_sha256": csc_sha}, f, indent=1)
 
     # --- fruit.ppm: the reference's own sample input (data file, not source)
     src = "/root/reference/data/fruit.ppm"
