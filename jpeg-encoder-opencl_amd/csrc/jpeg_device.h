@@ -21,6 +21,38 @@ struct Geom {
 inline size_t coef_dwords(const Geom& g) { return (size_t)g.tiles * 3 * 2048; }
 inline size_t unit_off_words(const Geom& g) { return (size_t)g.tiles * 192; }
 
+// Device pointers of the screened (integer-MFMA) pipeline, jpeg_screen_kernels.hip.
+struct ScreenParams {
+    const uint4* afrag;     // [4 row tiles][5 digits][64 lanes] 16 int8: MFMA A fragments of the fixed-point map
+    const double* qconst;   // [2 channel types][64 zig-zag positions][4] = {s1, thr1, s2, thr2}
+    const double* qd;       // [2][64] quantiser divisors as doubles, natural order
+    const uint32_t* lut;    // [4][256] Huffman LUTs (code << 5 | len)
+    uint2* meta;            // [frame][tile][chan][64] {arena word offset, aclen << 16 | (uint16)dc}
+    uint32_t* arena;        // AC bit strings, one word-aligned blob per unit
+    uint32_t arena_words;   // = grid * region_words + overflow pool
+    uint32_t region_words;  // private region of each persistent wave (bump-allocated without atomics)
+    uint32_t overflow_base; // first word of the shared overflow pool (= grid * region_words)
+    uint32_t* counters;     // [0] overflow-pool words used, [1] fix-up list length
+    uint32_t* fixlist;      // unit slot indices to recompute exactly
+    uint32_t fixcap;
+    uint32_t* status;
+    uint32_t* coefs;        // probe output (tiled coefficient layout) or nullptr
+    uint8_t* samples;       // probe output (padded YCbCr image, interleaved) or nullptr
+};
+
+// number of persistent single-wave workgroups launch_screen_encode will use
+uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves);
+hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,
+                                bool probe, uint32_t grid_waves, hipStream_t s);
+hipError_t launch_fixup(const Geom& g, const uint8_t* rgb, const ScreenParams& sp, bool probe,
+                        uint32_t grid_waves, hipStream_t s);
+hipError_t launch_meta_sizes(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* lut,
+                             uint32_t* unit_off, uint32_t* tile_bits, uint32_t* status, hipStream_t s);
+hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,
+                        const uint32_t* lut, const uint32_t* unit_off, const uint64_t* tile_off,
+                        uint8_t* out, uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,
+                        hipStream_t s);
+
 hipError_t launch_transform(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const double* qd,
                             uint32_t* coefs, int mode, hipStream_t s);
 hipError_t launch_probe_samples(const Geom& g, const uint8_t* rgb, uint8_t* samples, hipStream_t s);
@@ -29,7 +61,8 @@ hipError_t launch_unit_sizes(const Geom& g, uint32_t n_frames, const uint32_t* c
                              uint32_t* status, hipStream_t s);
 hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, const uint32_t* tile_bits,
                             uint64_t* tile_off, uint8_t* out, uint64_t out_stride,
-                            uint64_t* frame_bits, uint32_t* status, hipStream_t s);
+                            uint64_t* frame_bits, uint32_t* status, uint32_t* reset_counters,
+                            hipStream_t s);
 hipError_t launch_emit(const Geom& g, uint32_t n_frames, const uint32_t* coefs, const uint32_t* lut,
                        const uint32_t* unit_off, const uint64_t* tile_off, uint8_t* out,
                        uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,

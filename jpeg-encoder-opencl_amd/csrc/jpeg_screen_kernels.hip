@@ -1,0 +1,661 @@
+// Screened transform pipeline (gfx950 / CDNA4): the reference's in-place fp64 chain
+// evaluated as an exact fixed-point linear map on the int8 MFMA units, with a
+// rigorous accept/recompute test so that the results stay bit-identical.
+//
+// Why this is legal: in exact arithmetic the chain of
+// utils.cpp:314-348 is a fixed 64x64 linear map L of the level-shifted samples
+// p in [-128,127]^64.  The fp64 chain c the reference runs differs from L p only by
+// rounding, |c_k - (L p)_k| <= eps_k (forward error analysis,
+// tools/gen_screen_tables.py).  The kernel computes Lt p exactly, Lt = round(L*2^39)
+// split into five balanced int8 digits (|Lt - L| p <= 2^-27), so
+// |c_k/Q_k - z_k| <= tau_k with z_k = (Lt p)_k / Q_k.  The reference's quantiser
+// round(fl(c/Q)) equals round-half-away of the exact quotient, so
+// whenever z_k is farther than tau_k from every half-integer the quantised value
+// is decided.  Units with an undecided coefficient are recomputed by k_fixup with
+// the exact ordered fp64 chain -- that chain remains the arbiter.  Coefficient 0 is
+// always exact: row 0 of L is SCALE_00 * ones, so c_0 = fl(sum(p) * SCALE_00) is
+// formed directly.
+//
+// Pipeline per batch:
+//   k_screen_encode  RGB -> per-unit {DC, AC bit string (word-aligned blob in an arena)}
+//                    samples (integer-exact CSC), MFMA map, quantise+verify, LDS transpose to
+//                    zig-zag rows, per-unit RLE/Huffman walk into an LDS slot, blob store
+//   k_fixup          exact fp64 chain for the (rare) undecided / oversized units
+//   k_meta_sizes     DC code lengths + AC lengths -> tile-local offsets, tile sums
+//   k_tile_scan      (jpeg_kernels.hip) 64-bit scan of tile sums
+//   k_merge          DC symbols + AC blobs -> final bit string (LDS window per tile)
+#include "jpeg_devfn.h"
+#include "jpeg_screen_tables.h"  // kScreenLimbs, kScreenFracBits (the tables themselves are uploaded by the host)
+
+namespace mi355 {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kSlotWords = 54;      // LDS slot per unit: the worst case, so no unit is ever oversized
+constexpr uint32_t kSlotWordsFull = 54;  // worst case 63*(17+10)+4 = 1705 bits
+
+// ----------------------------------------------------------------------------
+// integer-exact colour conversion (performCSC, utils.cpp:92-110)
+//
+// Y  = (uint8)(0.299 R + 0.587 G + 0.114 B) evaluated in fp64 differs from the
+// decimal value (299R+587G+114B)/1000 by < 1e-13, so its truncation equals the
+// integer quotient unless the decimal value is itself an integer (remainder 0),
+// where the fp64 sum may land just below it: that case (1 pixel in 1000) is
+// evaluated in fp64.  For Cb/Cr, (c0 R + c1 G + c2 B)/1e6 + 128, the integer
+// quotient is exact for all 2^24 inputs.  Both statements are checked
+// exhaustively (tests: exhaustive colour conversion on the GPU path).
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t csc_int(int chan, uint32_t r, uint32_t g, uint32_t b) {
+    if (chan == 0) {
+        uint32_t s = 299u * r + 587u * g + 114u * b;  // <= 255000
+        uint32_t y = s / 1000u;
+        if (s - y * 1000u == 0u) y = csc1(r, g, b, 0.299, 0.587, 0.114, 0.0);
+        return y;
+    } else if (chan == 1) {
+        uint32_t s = 128000000u + 500000u * b - 168736u * r - 331264u * g;
+        return s / 1000000u;
+    } else {
+        uint32_t s = 128000000u + 500000u * r - 418688u * g - 81312u * b;
+        return s / 1000000u;
+    }
+}
+
+__device__ __forceinline__ uint32_t csc_int_at(const uint8_t* __restrict__ f, uint32_t W, uint32_t x,
+                                               uint32_t y, int chan) {
+    const uint8_t* p = f + ((size_t)y * W + x) * 3;
+    return csc_int(chan, p[0], p[1], p[2]);
+}
+
+// padded pixel (px,py) of channel chan, generic path (see sample_generic)
+__device__ __forceinline__ uint32_t sample_generic_int(const uint8_t* __restrict__ f, const Geom& g,
+                                                       int chan, bool avg, uint32_t px, uint32_t py) {
+    uint32_t mx = px < g.W ? px : 2 * g.W - 1 - px;
+    uint32_t my = py < g.H ? py : 2 * g.H - 1 - py;
+    if (avg) {
+        uint32_t qx = mx & ~1u, qy = my & ~1u;
+        if (qx + 1 < g.W && qy + 1 < g.H) {
+            uint32_t s = csc_int_at(f, g.W, qx, qy, chan) + csc_int_at(f, g.W, qx + 1, qy, chan) +
+                         csc_int_at(f, g.W, qx, qy + 1, chan) + csc_int_at(f, g.W, qx + 1, qy + 1, chan);
+            return s >> 2;
+        }
+    }
+    return csc_int_at(f, g.W, mx, my, chan);
+}
+
+// 16 samples = rows 2*gq, 2*gq+1 of block (bx,by), packed 4 per dword in sample
+// order (y*8+x), as unsigned bytes.
+template <int CHAN, bool FAST>
+__device__ __forceinline__ void load_rowpair(const uint8_t* __restrict__ f, const Geom& g, bool avg,
+                                             uint32_t bx, uint32_t by, uint32_t gq, uint32_t (&pk)[4]) {
+    if constexpr (FAST) {
+        uint32_t w[2][6];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint2* p =
+                reinterpret_cast<const uint2*>(f + ((size_t)(by * 8 + gq * 2 + r) * g.W + bx * 8) * 3);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                uint2 v = p[j];
+                w[r][2 * j] = v.x;
+                w[r][2 * j + 1] = v.y;
+            }
+        }
+        uint32_t val[2][8];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                uint32_t c[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    int byte = 3 * x + k;
+                    c[k] = (w[r][byte >> 2] >> (8 * (byte & 3))) & 255u;
+                }
+                val[r][x] = csc_int(CHAN, c[0], c[1], c[2]);
+            }
+        if (avg) {
+#pragma unroll
+            for (int x = 0; x < 8; x += 2) {
+                uint32_t m = (val[0][x] + val[0][x + 1] + val[1][x] + val[1][x + 1]) >> 2;
+                val[0][x] = val[0][x + 1] = val[1][x] = val[1][x + 1] = m;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                pk[r * 2 + h] = val[r][4 * h] | (val[r][4 * h + 1] << 8) | (val[r][4 * h + 2] << 16) |
+                                (val[r][4 * h + 3] << 24);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t v = 0;
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                int s = i * 4 + j;  // 0..15 within the row pair
+                uint32_t smp = sample_generic_int(f, g, CHAN, avg, bx * 8 + (s & 7), by * 8 + gq * 2 + (s >> 3));
+                v |= smp << (8 * j);
+            }
+            pk[i] = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// device-side parameter block
+// ----------------------------------------------------------------------------
+// (ScreenParams is declared in jpeg_device.h)
+
+struct SlotWriter {  // AC bits of one unit into the lane's LDS slot, layout [word][lane]
+    uint32_t* slot;   // &s_slot[lane]
+    uint32_t cap;     // words available
+    uint64_t acc;
+    uint32_t n;       // pending bits (< 32)
+    uint32_t w;       // words written
+    uint32_t bits;    // total bits
+    __device__ __forceinline__ void put(uint32_t code, uint32_t len) {
+        acc = (acc << len) | code;
+        n += len;
+        bits += len;
+        if (n >= 32) {
+            n -= 32;
+            if (w < cap) slot[w * 64] = (uint32_t)(acc >> n);
+            ++w;
+            acc &= (1ull << n) - 1;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        if (n) {
+            if (w < cap) slot[w * 64] = (uint32_t)(acc << (32 - n));
+            ++w;
+        }
+    }
+};
+
+// wave-wide inclusive prefix sum
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if ((int)lane >= d) v += t;
+    }
+    return v;
+}
+
+// Arena allocation for one wave.  Every persistent wave owns a private region and bumps a
+// private pointer (no atomics: a returning atomic on one address saturates at ~88 per
+// microsecond chip-wide, far below the wave-tile rate).  A wave whose region is full takes
+// chunks from the shared overflow pool with one atomic per chunk.
+constexpr uint32_t kOverflowChunk = 1024;  // words
+struct WaveArena {
+    uint32_t ptr, left;
+    // returns the base word of `need` words, or 0xFFFFFFFF if the arena is exhausted
+    __device__ __forceinline__ uint32_t take(const ScreenParams& sp, uint32_t need, uint32_t lane) {
+        if (need > left) {
+            uint32_t grab = need > kOverflowChunk ? need : kOverflowChunk;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(sp.counters, grab);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if ((uint64_t)sp.overflow_base + base + grab > sp.arena_words) return 0xFFFFFFFFu;
+            ptr = sp.overflow_base + base;
+            left = grab;
+        }
+        uint32_t r = ptr;
+        ptr += need;
+        left -= need;
+        return r;
+    }
+};
+
+// ----------------------------------------------------------------------------
+// k_screen_encode: persistent single-wave workgroups; one (tile, channel) per
+// iteration.  Lane roles: MFMA phase lane = (n = lane&15: block within a group of
+// 16, gq = lane>>4: row pair / accumulator row group); walk phase lane = block.
+// ----------------------------------------------------------------------------
+template <bool PROBE>
+__global__ void __launch_bounds__(64, 2)
+    k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
+    __shared__ uint32_t s_buf[kSlotWords * 64];  // transpose buffer [64][33] then AC slots [48][64]
+    __shared__ double s_qc[2][64][4];            // {s1, thr1, s2, thr2} per channel type and zig-zag position
+    __shared__ uint32_t s_act[2][256];           // AC code LUTs
+    __shared__ uint32_t s_flag[64];
+
+    const uint32_t lane = threadIdx.x, n = lane & 15, gq = lane >> 4;
+    for (uint32_t i = lane; i < 512; i += 64) {
+        (&s_qc[0][0][0])[i] = sp.qconst[i];
+        (&s_act[0][0])[i] = sp.lut[512 + i];
+    }
+    v4i A[4][kScreenLimbs];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int l = 0; l < kScreenLimbs; ++l) {
+            uint4 t = sp.afrag[(mt * kScreenLimbs + l) * 64 + lane];
+            A[mt][l] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+        }
+    __syncthreads();
+
+    WaveArena wa{blockIdx.x * sp.region_words, sp.region_words};
+    const uint32_t per_frame = g.tiles * 3;
+    const uint32_t total = per_frame * n_frames;
+    for (uint32_t wt = blockIdx.x; wt < total; wt += gridDim.x) {
+        const uint32_t frame = wt / per_frame, id = wt - frame * per_frame;
+        uint32_t tile, chan;
+        {   // XCD-aware: ids i, i+8, i+16 (same XCD when gridDim.x % 8 == 0) = the 3 channels of one tile
+            uint32_t full = (g.tiles / 8) * 24;
+            if (id < full) {
+                uint32_t grp = id / 24, w = id % 24;
+                tile = grp * 8 + (w & 7);
+                chan = w >> 3;
+            } else {
+                uint32_t r = id - full;
+                tile = (g.tiles / 8) * 8 + r / 3;
+                chan = r % 3;
+            }
+        }
+        const uint32_t ct = chan ? 1u : 0u;
+        const uint8_t* f = rgb + (size_t)frame * g.frame_stride;
+        const bool avg = (chan != 0) && (g.flags & 1u);
+        const size_t us_base = (((size_t)frame * g.tiles + tile) * 3 + chan) * 64;
+
+        // are all 64 blocks of this tile inside the image (no mirror padding)?
+        bool interior = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t b = tile * 64 + 16 * j + n;
+            b = b < g.N ? b : g.N - 1;
+            uint32_t by = b / g.nbx, bx = b - by * g.nbx;
+            interior = interior && (bx * 8 + 8 <= g.W) && (by * 8 + 8 <= g.H);
+        }
+        const bool fast = g.fast_rows && __all(interior);
+
+        s_flag[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            uint32_t b = tile * 64 + 16 * j + n;
+            b = b < g.N ? b : g.N - 1;
+            const uint32_t by = b / g.nbx, bx = b - by * g.nbx;
+            uint32_t pk[4] = {b, by, bx, gq};
+            if (g.flags & 0x400u) {
+            } else if (chan == 0) {
+                if (fast) load_rowpair<0, true>(f, g, false, bx, by, gq, pk);
+                else load_rowpair<0, false>(f, g, false, bx, by, gq, pk);
+            } else if (chan == 1) {
+                if (fast) load_rowpair<1, true>(f, g, avg, bx, by, gq, pk);
+                else load_rowpair<1, false>(f, g, avg, bx, by, gq, pk);
+            } else {
+                if (fast) load_rowpair<2, true>(f, g, avg, bx, by, gq, pk);
+                else load_rowpair<2, false>(f, g, avg, bx, by, gq, pk);
+            }
+            if constexpr (PROBE) {
+                if (sp.samples && tile * 64 + 16 * j + n < g.N) {
+#pragma unroll
+                    for (int sidx = 0; sidx < 16; ++sidx) {
+                        uint32_t v = (pk[sidx >> 2] >> (8 * (sidx & 3))) & 255u;
+                        size_t px = (size_t)(by * 8 + gq * 2 + (sidx >> 3)) * g.W8 + bx * 8 + (sidx & 7);
+                        sp.samples[((size_t)frame * g.W8 * g.H8 + px) * 3 + chan] = (uint8_t)v;
+                    }
+                }
+            }
+            // sum of the block's 64 samples (for the exact DC): 16 in this lane, then over the 4 row-pair lanes
+            uint32_t ssum = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ssum = __builtin_amdgcn_sad_u8(pk[i], 0u, ssum);
+            ssum += __shfl_xor(ssum, 16);
+            ssum += __shfl_xor(ssum, 32);
+            // level shift: sample - 128 as int8 == sample ^ 0x80
+            const v4i B = v4i{(int)(pk[0] ^ 0x80808080u), (int)(pk[1] ^ 0x80808080u),
+                              (int)(pk[2] ^ 0x80808080u), (int)(pk[3] ^ 0x80808080u)};
+
+            // exact coefficient 0: c0 = fl(sum * SCALE_00), q0 = round(c0 / Q0)   (utils.cpp:336,459)
+            const double c0 = (double)((int)ssum - 8192) * kScale00;
+            const int q0 = (int)__builtin_round(c0 / sp.qd[ct * 64]);
+
+            bool amb = false;
+            if (g.flags & 0x200u) {
+                s_buf[(16 * j + n) * 33 + gq] = pk[0] ^ pk[1] ^ pk[2] ^ pk[3] ^ ssum;
+                continue;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                v4i acc[kScreenLimbs];
+#pragma unroll
+                for (int l = 0; l < kScreenLimbs; ++l)
+                    acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mt][l], B, v4i{0, 0, 0, 0}, 0, 0, 0);
+                int q[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int hi = acc[4][r] * 256 + acc[3][r];
+                    const int mid = acc[2][r] * 256 + acc[1][r];
+                    const double y1 = (double)hi * 65536.0 + (double)mid;  // exact
+                    const double* qc = &s_qc[ct][16 * mt + 4 * gq + r][0];
+                    double z = y1 * qc[0];
+                    double t = __builtin_fabs(z) + 0.5;
+                    double fr = t - __builtin_floor(t);
+                    int nn = (int)t;
+                    bool a = !(__builtin_fabs(fr - 0.5) < qc[1]);
+                    if (a) {  // second look with the least significant digit included
+                        const double y2 = y1 * 256.0 + (double)acc[0][r];  // exact
+                        z = y2 * qc[2];
+                        t = __builtin_fabs(z) + 0.5;
+                        fr = t - __builtin_floor(t);
+                        nn = (int)t;
+                        a = !(__builtin_fabs(fr - 0.5) < qc[3]);
+                    }
+                    q[r] = z < 0.0 ? -nn : nn;
+                    if (mt == 0 && r == 0) {
+                        if (gq == 0) {
+                            q[r] = q0;
+                            a = false;
+                        }
+                    }
+                    amb = amb || a;
+                }
+                // zig-zag positions 16mt+4gq .. +3 of unit 16j+n -> transpose buffer
+                uint32_t* row = &s_buf[(16 * j + n) * 33 + 8 * mt + 2 * gq];
+                row[0] = ((uint32_t)q[0] & 0xffffu) | ((uint32_t)q[1] << 16);
+                row[1] = ((uint32_t)q[2] & 0xffffu) | ((uint32_t)q[3] << 16);
+            }
+            if (amb) s_flag[16 * j + n] = 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- walk phase: lane = block
+        const uint32_t b = tile * 64 + lane;
+        const bool active = b < g.N;
+        uint32_t c[32];
+#pragma unroll
+        for (int p = 0; p < 32; ++p) c[p] = s_buf[lane * 33 + p];
+        bool flagged = s_flag[lane] != 0;
+        __builtin_amdgcn_wave_barrier();  // s_buf is reused as the slot array below
+
+        if constexpr (PROBE) {
+            uint32_t* dst = sp.coefs + us_base / 64 * 2048 + lane;
+#pragma unroll
+            for (int p = 0; p < 32; ++p) dst[p * 64] = active ? c[p] : 0u;
+        }
+
+        SlotWriter sw{&s_buf[lane], kSlotWords, 0, 0, 0, 0};
+        auto put = [&](uint32_t code, uint32_t len) { sw.put(code, len); };
+        bool ok = true;
+        if (g.flags & 0x100u) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int p = 0; p < 32; ++p) x ^= c[p];
+            sw.put(x & 0xffffu, 16);
+        } else {
+            ok = walk_ac(c, s_act[ct], put);
+        }
+        const uint32_t aclen = sw.bits;
+        sw.flush();
+        if (sw.w > kSlotWords) flagged = true;  // oversized AC string: k_fixup has full-size slots
+        if (!active) flagged = false;
+        if (!ok && active && !flagged) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY (decided coefficients only)
+
+        const uint32_t nw = (active && !flagged) ? sw.w : 0u;
+        const uint32_t incl = wave_incl_scan(nw, lane);
+        const uint32_t base = wa.take(sp, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), lane);
+        const uint32_t off = base + incl - nw;
+        const bool fits = base != 0xFFFFFFFFu;
+        if (!fits) {
+            if (lane == 0) atomicOr(sp.status, 2u);  // MI355_E_CAPACITY
+        } else {
+            for (uint32_t w = 0; __any(w < nw); ++w)
+                if (w < nw) sp.arena[off + w] = s_buf[w * 64 + lane];
+        }
+        const int dc = (int)(int16_t)(c[0] & 0xffffu);
+        sp.meta[us_base + lane] = make_uint2(off, active ? ((aclen << 16) | ((uint32_t)dc & 0xffffu)) : 0u);
+        if (flagged) {
+            uint32_t k = atomicAdd(sp.counters + 1, 1u);
+            if (k < sp.fixcap) sp.fixlist[k] = (uint32_t)(us_base + lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ----------------------------------------------------------------------------
+// k_fixup: the exact ordered fp64 chain for listed units (lane = list entry).
+// ----------------------------------------------------------------------------
+template <bool PROBE>
+__global__ void __launch_bounds__(64)
+    k_fixup(Geom g, const uint8_t* __restrict__ rgb, ScreenParams sp) {
+    __shared__ uint32_t s_slot[kSlotWordsFull * 64];
+    __shared__ uint32_t s_act[2][256];
+    __shared__ uint32_t s_smp[16 * 64];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 512; i += 64) (&s_act[0][0])[i] = sp.lut[512 + i];
+    __syncthreads();
+    uint32_t count = sp.counters[1];
+    if (count > sp.fixcap) count = sp.fixcap;
+    for (uint32_t base = blockIdx.x * 64; base < count; base += gridDim.x * 64) {
+        const bool valid = base + lane < count;
+        const uint32_t us = sp.fixlist[valid ? base + lane : base];
+        const uint32_t ul = us & 63, wt = us >> 6;
+        const uint32_t chan = wt % 3, ft = wt / 3;
+        const uint32_t frame = ft / g.tiles, tile = ft - frame * g.tiles;
+        const uint32_t b = tile * 64 + ul;
+        const uint32_t by = b / g.nbx, bx = b - by * g.nbx;
+        const uint8_t* f = rgb + (size_t)frame * g.frame_stride;
+        const bool avg = (chan != 0) && (g.flags & 1u);
+        const double k0 = csc_k(chan, 0), k1 = csc_k(chan, 1), k2 = csc_k(chan, 2), k3 = csc_k(chan, 3);
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            uint32_t v = 0;
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                int s = i * 4 + j;
+                v |= sample_generic(f, g, avg, bx * 8 + (s & 7), by * 8 + (s >> 3), k0, k1, k2, k3) << (8 * j);
+            }
+            s_smp[i * 64 + lane] = v;
+        }
+        double P[64];
+#pragma unroll
+        for (int s = 0; s < 64; ++s)
+            P[s] = (double)((int)((s_smp[(s >> 2) * 64 + lane] >> (8 * (s & 3))) & 255u) - 128);
+        chain<1>(P);
+        const double* q = sp.qd + (chan ? 64 : 0);
+        int qi[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) qi[i] = (int)__builtin_round(P[i] / q[i]);
+        uint32_t c[32];
+#pragma unroll
+        for (int p = 0; p < 32; ++p)
+            c[p] = ((uint32_t)qi[zigzag_nat(2 * p)] & 0xffffu) | ((uint32_t)qi[zigzag_nat(2 * p + 1)] << 16);
+        if constexpr (PROBE) {
+            if (valid) {
+                uint32_t* dst = sp.coefs + (size_t)wt * 2048 + ul;
+#pragma unroll
+                for (int p = 0; p < 32; ++p) dst[p * 64] = c[p];
+            }
+        }
+        SlotWriter sw{&s_slot[lane], kSlotWordsFull, 0, 0, 0, 0};
+        auto put = [&](uint32_t code, uint32_t len) { sw.put(code, len); };
+        bool ok = walk_ac(c, s_act[chan ? 1 : 0], put);
+        const uint32_t aclen = sw.bits;
+        sw.flush();
+        if (valid) {
+            if (!ok) atomicOr(sp.status, 1u);
+            const uint32_t nw = sw.w;
+            const uint32_t off = sp.overflow_base + (nw ? atomicAdd(sp.counters, nw) : 0u);
+            if ((uint64_t)off + nw > sp.arena_words) {
+                atomicOr(sp.status, 2u);
+            } else {
+                for (uint32_t w = 0; w < nw; ++w) sp.arena[off + w] = s_slot[w * 64 + lane];
+            }
+            const int dc = (int)(int16_t)(c[0] & 0xffffu);
+            sp.meta[us] = make_uint2(off, (aclen << 16) | ((uint32_t)dc & 0xffffu));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ----------------------------------------------------------------------------
+// k_meta_sizes: workgroup = tile (wave = channel, lane = block): total bits per
+// unit = DC symbol + AC string; tile-local exclusive offsets + tile sums.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ int meta_dc(uint32_t y) { return (int)(int16_t)(y & 0xffffu); }
+
+__device__ __forceinline__ int meta_pred(const uint2* __restrict__ meta, size_t frame_tile0, uint32_t tile,
+                                         uint32_t chan, uint32_t lane, int own_dc) {
+    int prev = __shfl_up(own_dc, 1);
+    if (lane == 0) {
+        prev = 0;
+        if (tile > 0) prev = meta_dc(meta[((frame_tile0 + tile - 1) * 3 + chan) * 64 + 63].y);
+    }
+    return prev;
+}
+
+__global__ void __launch_bounds__(192)
+    k_meta_sizes(Geom g, const uint2* __restrict__ meta, const uint32_t* __restrict__ lut,
+                 uint32_t* __restrict__ unit_off, uint32_t* __restrict__ tile_bits,
+                 uint32_t* __restrict__ status) {
+    __shared__ uint32_t s_dc[2][16];
+    __shared__ uint32_t s_bits[192];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
+    const uint32_t tile = blockIdx.x, frame = blockIdx.y;
+    if (tid < 32) s_dc[tid >> 4][tid & 15] = lut[(tid >> 4) * 256 + (tid & 15)];
+    __syncthreads();
+    const size_t ft0 = (size_t)frame * g.tiles;
+    const uint2 m = meta[((ft0 + tile) * 3 + chan) * 64 + lane];
+    const int dc = meta_dc(m.y);
+    const int pred = meta_pred(meta, ft0, tile, chan, lane, dc);
+    const bool active = tile * 64 + lane < g.N;
+    uint32_t bits = m.y >> 16;
+    auto count = [&](uint32_t, uint32_t len) { bits += len; };
+    bool ok = put_dc(dc - pred, s_dc[chan ? 1 : 0], count);
+    if (!active) {
+        bits = 0;
+        ok = true;
+    }
+    if (!ok) atomicOr(status, 1u);
+    s_bits[lane * 3 + chan] = bits;
+    __syncthreads();
+    if (tid < 64) {
+        uint32_t a0 = s_bits[tid * 3], a1 = s_bits[tid * 3 + 1], a2 = s_bits[tid * 3 + 2];
+        uint32_t blk = a0 + a1 + a2;
+        uint32_t incl = wave_incl_scan(blk, tid);
+        uint32_t excl = incl - blk;
+        uint32_t* uo = unit_off + (ft0 + tile) * 192 + tid * 3;
+        uo[0] = excl;
+        uo[1] = excl + a0;
+        uo[2] = excl + a0 + a1;
+        if (tid == 63) tile_bits[ft0 + tile] = incl;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// k_merge: like k_emit, but the AC bits come ready-made from the arena.
+// ----------------------------------------------------------------------------
+template <typename Writer>
+__device__ __forceinline__ void merge_unit(Writer& bw, int diff, const uint32_t* dct,
+                                           const uint32_t* __restrict__ arena, uint32_t off, uint32_t aclen) {
+    auto put = [&](uint32_t code, uint32_t len) { bw.put(code, len); };
+    put_dc(diff, dct, put);
+    for (uint32_t done = 0; done < aclen; done += 32) {
+        uint32_t w = arena[off + (done >> 5)];
+        uint32_t len = aclen - done < 32 ? aclen - done : 32;
+        bw.put(w >> (32 - len), len);
+    }
+    bw.flush();
+}
+
+__global__ void __launch_bounds__(192)
+    k_merge(Geom g, const uint2* __restrict__ meta, const uint32_t* __restrict__ arena,
+            const uint32_t* __restrict__ lut, const uint32_t* __restrict__ unit_off,
+            const uint64_t* __restrict__ tile_off, uint8_t* __restrict__ out, uint64_t out_stride,
+            const uint32_t* __restrict__ status, uint32_t lds_words_limit) {
+    __shared__ uint32_t s_dc[2][16];
+    __shared__ uint32_t s_words[kEmitLdsWords];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
+    const uint32_t tile = blockIdx.x, frame = blockIdx.y;
+    if (*status) return;
+    const size_t ft0 = (size_t)frame * g.tiles;
+    const uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
+    const uint64_t start = to[tile], end = to[tile + 1];
+    const uint64_t w0 = start >> 5;
+    const uint32_t nw = (uint32_t)(((end + 31) >> 5) - w0);
+    const bool use_lds = nw <= lds_words_limit;
+    uint32_t* outw = reinterpret_cast<uint32_t*>(out + (size_t)frame * out_stride);
+    const bool last_tile = tile + 1 == g.tiles;
+    if (tid < 32) s_dc[tid >> 4][tid & 15] = lut[(tid >> 4) * 256 + (tid & 15)];
+    if (use_lds) {
+        for (uint32_t i = tid; i < nw; i += 192) s_words[i] = 0;
+    } else {
+        for (uint32_t i = tid; i < nw; i += 192) {
+            bool shared = (i == 0 && (start & 31)) || (i == nw - 1 && (end & 31) && !last_tile);
+            if (!shared) __hip_atomic_store(&outw[w0 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (tile * 64 + lane < g.N) {
+        const uint2 m = meta[((ft0 + tile) * 3 + chan) * 64 + lane];
+        const int dc = meta_dc(m.y);
+        const int pred = meta_pred(meta, ft0, tile, chan, lane, dc);
+        const uint32_t off = unit_off[(ft0 + tile) * 192 + lane * 3 + chan];
+        const uint64_t pos = (start & 31) + off;
+        if (use_lds) {
+            BitWriterLds bw{s_words, 0, (uint32_t)(pos & 31), (uint32_t)(pos >> 5)};
+            merge_unit(bw, dc - pred, s_dc[chan ? 1 : 0], arena, m.x, m.y >> 16);
+        } else {
+            BitWriterGlobal bw{outw, 0, (uint32_t)(pos & 31), w0 + (pos >> 5)};
+            merge_unit(bw, dc - pred, s_dc[chan ? 1 : 0], arena, m.x, m.y >> 16);
+        }
+    }
+    if (!use_lds) return;
+    __syncthreads();
+    for (uint32_t i = tid; i < nw; i += 192) {
+        uint32_t v = __builtin_bswap32(s_words[i]);
+        bool shared = (i == 0 && (start & 31)) || (i == nw - 1 && (end & 31) && !last_tile);
+        if (shared) {
+            if (v) atomicOr(&outw[w0 + i], v);
+        } else {
+            outw[w0 + i] = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// launchers
+// ----------------------------------------------------------------------------
+uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves) {
+    uint32_t total = g.tiles * 3 * n_frames;
+    uint32_t grid = total < max_waves ? total : max_waves;
+    if (grid > 8) grid &= ~7u;  // keep blockIdx.x % 8 stable across the grid-stride loop
+    return grid;
+}
+hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,
+                                bool probe, uint32_t grid_waves, hipStream_t s) {
+    uint32_t grid = screen_grid(g, n_frames, grid_waves);
+    if (probe)
+        hipLaunchKernelGGL((k_screen_encode<true>), dim3(grid), dim3(64), 0, s, g, n_frames, rgb, sp);
+    else
+        hipLaunchKernelGGL((k_screen_encode<false>), dim3(grid), dim3(64), 0, s, g, n_frames, rgb, sp);
+    return hipGetLastError();
+}
+hipError_t launch_fixup(const Geom& g, const uint8_t* rgb, const ScreenParams& sp, bool probe,
+                        uint32_t grid_waves, hipStream_t s) {
+    if (probe)
+        hipLaunchKernelGGL((k_fixup<true>), dim3(grid_waves), dim3(64), 0, s, g, rgb, sp);
+    else
+        hipLaunchKernelGGL((k_fixup<false>), dim3(grid_waves), dim3(64), 0, s, g, rgb, sp);
+    return hipGetLastError();
+}
+hipError_t launch_meta_sizes(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* lut,
+                             uint32_t* unit_off, uint32_t* tile_bits, uint32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(k_meta_sizes, dim3(g.tiles, n_frames), dim3(192), 0, s, g, meta, lut, unit_off,
+                       tile_bits, status);
+    return hipGetLastError();
+}
+hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,
+                        const uint32_t* lut, const uint32_t* unit_off, const uint64_t* tile_off,
+                        uint8_t* out, uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,
+                        hipStream_t s) {
+    if (lds_words_limit > kEmitLdsWords) lds_words_limit = kEmitLdsWords;
+    hipLaunchKernelGGL(k_merge, dim3(g.tiles, n_frames), dim3(192), 0, s, g, meta, arena, lut, unit_off,
+                       tile_off, out, out_stride, status, lds_words_limit);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

@@ -14,7 +14,10 @@
 #include <new>
 #include <vector>
 
+#include <cmath>
+
 #include "jpeg_device.h"
+#include "jpeg_screen_tables.h"
 #include "jpeg_tables.h"
 
 using namespace mi355;
@@ -128,7 +131,19 @@ struct mi355_jpeg_ctx {
     size_t out_cap = 0;
     uint64_t* d_bits = nullptr;
     size_t bits_cap = 0;
-    int transform_mode = 0;
+    // screened (integer-MFMA) pipeline
+    uint4* d_afrag = nullptr;       // MFMA A fragments of the fixed-point map (static)
+    double* d_qconst = nullptr;     // [2][64][4] accept thresholds for the current tables
+    uint32_t* d_counters = nullptr; // [0] arena words, [1] fix-up list length
+    uint2* d_meta = nullptr;
+    size_t meta_cap = 0;
+    uint32_t* d_arena = nullptr;
+    size_t arena_cap = 0;           // words
+    uint32_t* d_fixlist = nullptr;
+    size_t fixlist_cap = 0;
+    double tau_scale = 1.0;         // debug: widen the accept margins to force fix-ups
+    uint32_t screen_waves = 2048;   // persistent single-wave workgroups of k_screen_encode
+    int transform_mode = 2;         // 0 exact fp64 chain (unrolled), 1 exact (looped), 2 screened MFMA + exact fix-up
     uint32_t emit_lds_words = 4096;
     int profiling = 0;              // 0 off, 1 all stages, 2 transform only
     std::vector<EventSet> ev_pool;  // grown on demand, reused after a reset
@@ -168,6 +183,40 @@ int upload_tables(mi355_jpeg_ctx* c) {
             lut[t * 256 + i] = c->huff[t].len[i] ? ((c->huff[t].code[i] << 5) | c->huff[t].len[i]) : 0u;
     HIP_TRY(hipMemcpy(c->d_q, q, sizeof q, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    // Accept thresholds of the screened transform (jpeg_screen_kernels.hip), per channel type
+    // and zig-zag position R, for z = (fixed-point map)/Q:
+    //   first look  (top four digits):  |c/Q - z1| <= (2^-19 + eps_R + fixerr)/Q + fp slop
+    //   second look (all five digits):  |c/Q - z2| <= (eps_R + fixerr)/Q + fp slop
+    // fp slop: z = y*s (relative 2^-52 of |z| < 2^12) and |z|+0.5 (2^-41): 2^-38 covers both.
+    static const uint8_t zz[64] = MI355_ZIGZAG_TABLE;
+    double qc[2][64][4];
+    for (int ct = 0; ct < 2; ++ct)
+        for (int R = 0; R < 64; ++R) {
+            const double Q = (double)(ct ? c->qchrom[zz[R]] : c->qlum[zz[R]]);
+            const double delta = kScreenEps[R] + kScreenFixErr;
+            const double slop = std::ldexp(1.0, -38);
+            double tau1 = ((std::ldexp(1.0, -19) + delta) / Q * 1.000001 + slop) * c->tau_scale;
+            double tau2 = (delta / Q * 1.000001 + slop) * c->tau_scale;
+            qc[ct][R][0] = std::ldexp(1.0, 8 - kScreenFracBits) / Q;
+            qc[ct][R][1] = tau1 < 0.5 ? 0.5 - tau1 : -1.0;  // -1: never accepted
+            qc[ct][R][2] = std::ldexp(1.0, -kScreenFracBits) / Q;
+            qc[ct][R][3] = tau2 < 0.5 ? 0.5 - tau2 : -1.0;
+        }
+    HIP_TRY(hipMemcpy(c->d_qconst, qc, sizeof qc, hipMemcpyHostToDevice));
+    return MI355_OK;
+}
+
+// MFMA A fragments of the fixed-point map: fragment (mt, digit), lane l = (m = l & 15, g = l >> 4)
+// holds row 16*mt + m (a zig-zag position), input samples 16*g .. 16*g+15.
+int upload_afrag(mi355_jpeg_ctx* c) {
+    std::vector<int8_t> h((size_t)4 * kScreenLimbs * 64 * 16);
+    for (int mt = 0; mt < 4; ++mt)
+        for (int l = 0; l < kScreenLimbs; ++l)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 16; ++i)
+                    h[(((size_t)mt * kScreenLimbs + l) * 64 + lane) * 16 + i] =
+                        kScreenLimb[l][16 * mt + (lane & 15)][16 * (lane >> 4) + i];
+    HIP_TRY(hipMemcpy(c->d_afrag, h.data(), h.size(), hipMemcpyHostToDevice));
     return MI355_OK;
 }
 
@@ -202,6 +251,52 @@ int ensure_workspace(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames) {
 constexpr size_t kMaxEventSets = 1u << 16;
 
 // slot 0 opens a new event set for this call
+// workspace of the screened pipeline; arena_words: capacity for the AC blobs
+int ensure_screen_workspace(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, size_t arena_words) {
+    int e;
+    size_t slots = (size_t)g.tiles * 3 * 64 * n_frames;
+    if ((e = ensure(c->d_meta, c->meta_cap, slots))) return e;
+    if ((e = ensure(c->d_fixlist, c->fixlist_cap, slots))) return e;
+    if ((e = ensure(c->d_arena, c->arena_cap, arena_words))) return e;
+    return MI355_OK;
+}
+
+// Arena geometry for a payload bound of `need_words`: one private region per persistent wave
+// plus an overflow pool that alone could hold everything (chunked, hence the extra slack).
+struct ArenaPlan {
+    uint32_t grid, region_words;
+    size_t total_words;
+};
+ArenaPlan plan_arena(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, size_t need_words) {
+    ArenaPlan p;
+    p.grid = screen_grid(g, n_frames, c->screen_waves);
+    p.region_words = (uint32_t)((need_words + p.grid - 1) / p.grid);
+    p.total_words = (size_t)p.grid * p.region_words + need_words + (size_t)p.grid * 1024 + 64;
+    return p;
+}
+
+ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const ArenaPlan& plan,
+                           uint32_t* coefs) {
+    ScreenParams sp;
+    const size_t arena_words = plan.total_words;
+    sp.region_words = plan.region_words;
+    sp.overflow_base = plan.grid * plan.region_words;
+    sp.afrag = c->d_afrag;
+    sp.qconst = c->d_qconst;
+    sp.qd = c->d_q;
+    sp.lut = c->d_lut;
+    sp.meta = c->d_meta;
+    sp.arena = c->d_arena;
+    sp.arena_words = (uint32_t)(arena_words > 0xFFFFFFFFull ? 0xFFFFFFFFull : arena_words);
+    sp.counters = c->d_counters;
+    sp.fixlist = c->d_fixlist;
+    sp.fixcap = (uint32_t)((size_t)g.tiles * 3 * 64 * n_frames);
+    sp.status = c->d_status;
+    sp.coefs = coefs;
+    sp.samples = nullptr;
+    return sp;
+}
+
 void record(mi355_jpeg_ctx* c, int i, hipStream_t s) {
     if (!c->profiling) return;
     if (c->profiling == 2 && i > 1) return;
@@ -248,11 +343,50 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
                               c->d_status, s));
     record(c, 2, s);
     HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
-                             c->d_status, s));
+                             c->d_status, nullptr, s));
     record(c, 3, s);
     HIP_TRY(launch_emit(g, n_frames, c->d_coefs, c->d_lut, c->d_unit_off, c->d_tile_off, d_out,
                         out_stride, c->d_status, c->emit_lds_words, s));
     record(c, 4, s);
+    return MI355_OK;
+}
+
+// Screened pipeline: k_screen_encode -> k_fixup -> k_meta_sizes -> k_tile_scan -> k_merge.
+// The event slots keep their meaning: [0,1] transform (+ fix-up), [1,2] sizes, [2,3] scan, [3,4] emit.
+int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t* d_rgb, uint8_t* d_out,
+                 size_t out_stride, uint64_t* d_bits, hipStream_t s) {
+    // AC blobs are word aligned per unit: at most total_bits/32 + one word per unit
+    ArenaPlan plan = plan_arena(c, g, n_frames, (size_t)n_frames * (out_stride / 4 + (size_t)g.N * 3));
+    if (plan.total_words > 0xFFFFFFFFull) return MI355_E_ARG;  // 32-bit word offsets: split the batch
+    int e;
+    if ((e = ensure_screen_workspace(c, g, n_frames, plan.total_words))) return e;
+    ScreenParams sp = screen_params(c, g, n_frames, plan, nullptr);
+    record(c, 0, s);
+    HIP_TRY(launch_screen_encode(g, n_frames, d_rgb, sp, false, c->screen_waves, s));
+    HIP_TRY(launch_fixup(g, d_rgb, sp, false, 256, s));
+    record(c, 1, s);
+    HIP_TRY(launch_meta_sizes(g, n_frames, c->d_meta, c->d_lut, c->d_unit_off, c->d_tile_bits, c->d_status, s));
+    record(c, 2, s);
+    HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
+                             c->d_status, c->d_counters, s));
+    record(c, 3, s);
+    HIP_TRY(launch_merge(g, n_frames, c->d_meta, c->d_arena, c->d_lut, c->d_unit_off, c->d_tile_off, d_out,
+                         out_stride, c->d_status, c->emit_lds_words, s));
+    record(c, 4, s);
+    return MI355_OK;
+}
+
+// Screened transform only (stage probes): coefficients into the tiled workspace layout.
+int run_screened_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, uint8_t* d_samples, hipStream_t s) {
+    ArenaPlan plan = plan_arena(c, g, 1, (size_t)g.N * 3 * 54);
+    if (plan.total_words > 0xFFFFFFFFull) return MI355_E_ARG;
+    int e;
+    if ((e = ensure_screen_workspace(c, g, 1, plan.total_words))) return e;
+    ScreenParams sp = screen_params(c, g, 1, plan, c->d_coefs);
+    sp.samples = d_samples;
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(uint32_t), s));
+    HIP_TRY(launch_screen_encode(g, 1, d_rgb, sp, true, c->screen_waves, s));
+    HIP_TRY(launch_fixup(g, d_rgb, sp, true, 256, s));
     return MI355_OK;
 }
 
@@ -304,12 +438,21 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     if (m) c->transform_mode = atoi(m);
     const char* l = getenv("MI355_JPEG_EMIT_LDS_WORDS");
     if (l) c->emit_lds_words = (uint32_t)atoi(l);
+    const char* ts = getenv("MI355_JPEG_SCREEN_TAU_SCALE");
+    if (ts) c->tau_scale = atof(ts);
+    const char* sw = getenv("MI355_JPEG_SCREEN_WAVES");
+    if (sw && atoi(sw) > 0) c->screen_waves = (uint32_t)atoi(sw);
     int e = MI355_OK;
     if (hipMalloc((void**)&c->d_q, 128 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut, 1024 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_status, sizeof(uint32_t)) != hipSuccess)
+        hipMalloc((void**)&c->d_status, sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->d_afrag, (size_t)4 * kScreenLimbs * 64 * 16) != hipSuccess ||
+        hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&c->d_counters, 2 * sizeof(uint32_t)) != hipSuccess)
         e = MI355_E_ALLOC;
     if (!e) e = hip_err(hipMemset(c->d_status, 0, sizeof(uint32_t)));
+    if (!e) e = hip_err(hipMemset(c->d_counters, 0, 2 * sizeof(uint32_t)));
+    if (!e) e = upload_afrag(c);
     if (!e) e = upload_tables(c);
     if (e) {
         mi355_jpeg_destroy(c);
@@ -322,8 +465,9 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
 void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->d_q, c->d_lut, c->d_status, c->d_coefs, c->d_unit_off, c->d_tile_bits,
-                    c->d_tile_off, c->d_in, c->d_out, c->d_bits};
+    void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
+                    c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
+                    c->d_counters, c->d_meta,     c->d_arena,  c->d_fixlist};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& es : c->ev_pool)
@@ -408,6 +552,13 @@ int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t
     if (n_frames > 65535u) return MI355_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->transform_mode == 2) {
+        // only unit_off / tile arrays of the classic workspace are needed
+        if ((e = ensure(c->d_unit_off, c->unit_off_cap, unit_off_words(g) * n_frames))) return e;
+        if ((e = ensure(c->d_tile_bits, c->tiles_cap, (size_t)g.tiles * n_frames))) return e;
+        if ((e = ensure(c->d_tile_off, c->tile_off_cap, ((size_t)g.tiles + 1) * n_frames))) return e;
+        return run_screened(c, g, n_frames, (const uint8_t*)d_rgb, (uint8_t*)d_out, out_stride, d_bits, s);
+    }
     if ((e = ensure_workspace(c, g, n_frames))) return e;
     record(c, 0, s);
     HIP_TRY(launch_transform(g, n_frames, (const uint8_t*)d_rgb, c->d_q, c->d_coefs, c->transform_mode, s));
@@ -466,7 +617,13 @@ int mi355_jpeg_probe_samples(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, 
     if ((e = ensure(c->d_in, c->in_cap, (size_t)g.frame_stride))) return e;
     if ((e = ensure(c->d_out, c->out_cap, ob))) return e;
     HIP_TRY(hipMemcpy(c->d_in, rgb, g.frame_stride, hipMemcpyHostToDevice));
-    HIP_TRY(launch_probe_samples(g, c->d_in, c->d_out, nullptr));
+    if (c->transform_mode == 2) {
+        // the screened pipeline has its own (integer-exact) sample stage: probe that one
+        if ((e = ensure_workspace(c, g, 1))) return e;
+        if ((e = run_screened_probe(c, g, c->d_in, c->d_out, nullptr))) return e;
+    } else {
+        HIP_TRY(launch_probe_samples(g, c->d_in, c->d_out, nullptr));
+    }
     HIP_TRY(hipMemcpy(out, c->d_out, ob, hipMemcpyDeviceToHost));
     return MI355_OK;
 }
@@ -479,6 +636,7 @@ static int transform_to_workspace(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_
     if ((e = ensure(c->d_in, c->in_cap, (size_t)g->frame_stride))) return e;
     if ((e = ensure_workspace(c, *g, 1))) return e;
     HIP_TRY(hipMemcpy(c->d_in, rgb, g->frame_stride, hipMemcpyHostToDevice));
+    if (c->transform_mode == 2) return run_screened_probe(c, *g, c->d_in, nullptr, nullptr);
     HIP_TRY(launch_transform(*g, 1, c->d_in, c->d_q, c->d_coefs, c->transform_mode, nullptr));
     return MI355_OK;
 }

@@ -158,16 +158,92 @@ def test_emit_direct_path_equals_lds_path(jpeg, monkeypatch):
         assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits), words
 
 
-def test_transform_loop_variant_is_bit_identical(jpeg, monkeypatch):
-    rgb = ol.lcg_frame(512, 512, 9)
-    ql, qc = ol.quant_tables(50)
-    o = ol.oracle_encode(rgb, ql, qc, True, ol.KEEP_ZIGZAG)
-    for mode in ("0", "1"):
-        monkeypatch.setenv("MI355_JPEG_TRANSFORM_MODE", mode)
-        e2 = jpeg.Encoder(0)
+def test_all_transform_modes_are_bit_identical(jpeg, monkeypatch):
+    """mode 0/1: the exact ordered fp64 chain (unrolled / looped); mode 2 (default): the
+    integer-MFMA screened transform with exact fix-up.  Same bits from all three, on a
+    ragged size and on an aligned one."""
+    for (W, H, q, cds) in [(512, 512, 50, True), (253, 254, 90, False)]:
+        rgb = ol.lcg_frame(W, H, 9)
+        ql, qc = ol.quant_tables(q)
+        o = ol.oracle_encode(rgb, ql, qc, cds, KEEP)
+        flags = jpeg.F_CDS if cds else 0
+        for mode in ("0", "1", "2"):
+            monkeypatch.setenv("MI355_JPEG_TRANSFORM_MODE", mode)
+            e2 = jpeg.Encoder(0)
+            e2.set_quant(ql, qc)
+            assert np.array_equal(e2.probe_samples(rgb, flags), o.padded), mode
+            assert np.array_equal(e2.probe_coefficients(rgb, flags).astype(np.int32), o.zigzag), mode
+            assert np.array_equal(e2.probe_unit_bits(rgb, flags), o.unit_bits), mode
+            bits, nb = e2.encode_scan(rgb, flags)
+            assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits), mode
+            e2.close()
+
+
+@pytest.mark.parametrize("scale", ["3e3", "1e5", "1e9"])
+def test_screened_transform_forced_fixups(jpeg, monkeypatch, scale):
+    """The screened transform accepts a coefficient only when it is provably decided;
+    everything else goes through the exact fp64 chain (k_fixup).  Widening the accept
+    margin by a debug factor forces some / most / all units down that path: the output
+    must not change."""
+    monkeypatch.setenv("MI355_JPEG_SCREEN_TAU_SCALE", scale)
+    e2 = jpeg.Encoder(0)
+    for (W, H, q, cds) in [(640, 360, 50, True), (100, 37, 90, False)]:
+        rgb = ol.lcg_frame(W, H, 4)
+        ql, qc = ol.quant_tables(q)
         e2.set_quant(ql, qc)
-        assert np.array_equal(e2.probe_coefficients(rgb).astype(np.int32), o.zigzag), mode
-        e2.close()
+        o = ol.oracle_encode(rgb, ql, qc, cds, KEEP)
+        flags = jpeg.F_CDS if cds else 0
+        assert np.array_equal(e2.probe_coefficients(rgb, flags).astype(np.int32), o.zigzag)
+        bits, nb = e2.encode_scan(rgb, flags)
+        assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits)
+    e2.close()
+
+
+def test_exhaustive_colour_conversion_on_gpu(jpeg, enc):
+    """All 2^24 RGB triples through the product's integer-exact CSC (the screened
+    pipeline's sample stage) against the reference's output hash."""
+    import json
+    with open(os.path.join(GOLD, "tables.json")) as f:
+        want = json.load(f)["csc_exhaustive_sha256"]
+    i = np.arange(1 << 24, dtype=np.uint32)
+    px = np.stack([(i >> 16) & 255, (i >> 8) & 255, i & 255], -1).astype(np.uint8).reshape(4096, 4096, 3)
+    got = enc.probe_samples(px, 0)  # no chroma averaging, no padding: pure performCSC
+    assert hashlib.sha256(got.tobytes()).hexdigest() == want
+
+
+def test_structured_near_tie_inputs(jpeg, enc):
+    """Inputs built to land coefficients on or next to rounding boundaries: constant
+    blocks (DC = 8*(level-128); with Q=16 every level that is 8 mod 16 sits exactly at
+    k+0.5 in a true DCT and just below it in the reference's arithmetic), saturated and
+    two-level blocks, at q=50, q=100 (Q=1: every half-integer is a boundary) and q=1."""
+    H, W = 64, 256
+    rng = np.random.default_rng(8)
+    rgb = np.zeros((H, W, 3), np.uint8)
+    for by in range(H // 8):
+        for bx in range(W // 8):
+            kind = (by * (W // 8) + bx) % 4
+            blk = np.zeros((8, 8, 3), np.uint8)
+            if kind == 0:
+                blk[:] = rng.integers(0, 256)
+            elif kind == 1:
+                blk[:] = 8 + 16 * rng.integers(0, 15)
+            elif kind == 2:
+                blk[:, :4] = 0
+                blk[:, 4:] = 255
+            else:
+                blk[:] = rng.choice([0, 255], (8, 8, 1))
+            rgb[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] = blk
+    for q in (50, 100, 1):
+        ql, qc = set_quality(enc, q)
+        try:
+            o = ol.oracle_encode(rgb, ql, qc, True, KEEP)
+        except RuntimeError:
+            with pytest.raises(jpeg.JpegError):
+                enc.encode_scan(rgb)
+            continue
+        assert np.array_equal(enc.probe_coefficients(rgb).astype(np.int32), o.zigzag), q
+        bits, nb = enc.encode_scan(rgb)
+        assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits), q
 
 
 def test_batch_equals_single_frames(jpeg, enc):

@@ -66,7 +66,7 @@ def main():
     W, H = 3840, 2160
     rgb = ol.lcg_frame(W, H, 1)
     ql, qc = ol.quant_tables(50)
-    for mode in (0, 1):
+    for mode in (2, 0):
         os.environ["MI355_JPEG_TRANSFORM_MODE"] = str(mode)
         e2 = jpeg.Encoder(0)
         e2.set_quant(ql, qc)
