@@ -31,7 +31,6 @@ namespace mi355 {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr uint32_t kSlotWords = 54;      // LDS slot per unit: the worst case, so no unit is ever oversized
 constexpr uint32_t kSlotWordsFull = 54;  // worst case 63*(17+10)+4 = 1705 bits
 
 // ----------------------------------------------------------------------------
@@ -82,62 +81,69 @@ __device__ __forceinline__ uint32_t sample_generic_int(const uint8_t* __restrict
     return csc_int_at(f, g.W, mx, my, chan);
 }
 
-// 16 samples = rows 2*gq, 2*gq+1 of block (bx,by), packed 4 per dword in sample
-// order (y*8+x), as unsigned bytes.
-template <int CHAN, bool FAST>
-__device__ __forceinline__ void load_rowpair(const uint8_t* __restrict__ f, const Geom& g, bool avg,
-                                             uint32_t bx, uint32_t by, uint32_t gq, uint32_t (&pk)[4]) {
-    if constexpr (FAST) {
-        uint32_t w[2][6];
+// Raw RGB of rows 2*gq, 2*gq+1 of block (bx,by): 2 x 24 bytes as six 8-byte loads (fast
+// path: the block lies inside the image and rows are 8-byte aligned).
+__device__ __forceinline__ void load_raw_rowpair(const uint8_t* __restrict__ f, const Geom& g, uint32_t bx,
+                                                 uint32_t by, uint32_t gq, uint32_t (&w)[12]) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint2* p =
-                reinterpret_cast<const uint2*>(f + ((size_t)(by * 8 + gq * 2 + r) * g.W + bx * 8) * 3);
+    for (int r = 0; r < 2; ++r) {
+        const uint2* p =
+            reinterpret_cast<const uint2*>(f + ((size_t)(by * 8 + gq * 2 + r) * g.W + bx * 8) * 3);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                uint2 v = p[j];
-                w[r][2 * j] = v.x;
-                w[r][2 * j + 1] = v.y;
-            }
+        for (int j = 0; j < 3; ++j) {
+            uint2 v = p[j];
+            w[r * 6 + 2 * j] = v.x;
+            w[r * 6 + 2 * j + 1] = v.y;
         }
-        uint32_t val[2][8];
+    }
+}
+
+// 16 samples of channel CHAN from the raw row pair, packed 4 per dword in sample order
+// (y*8+x), as unsigned bytes; chroma averaging over the 2x2 quads of the row pair.
+template <int CHAN>
+__device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool avg, uint32_t (&pk)[4]) {
+    uint32_t val[2][8];
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                uint32_t c[3];
+        for (int x = 0; x < 8; ++x) {
+            uint32_t c[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    int byte = 3 * x + k;
-                    c[k] = (w[r][byte >> 2] >> (8 * (byte & 3))) & 255u;
-                }
-                val[r][x] = csc_int(CHAN, c[0], c[1], c[2]);
+            for (int k = 0; k < 3; ++k) {
+                int byte = 3 * x + k;
+                c[k] = (w[r * 6 + (byte >> 2)] >> (8 * (byte & 3))) & 255u;
             }
-        if (avg) {
-#pragma unroll
-            for (int x = 0; x < 8; x += 2) {
-                uint32_t m = (val[0][x] + val[0][x + 1] + val[1][x] + val[1][x + 1]) >> 2;
-                val[0][x] = val[0][x + 1] = val[1][x] = val[1][x + 1] = m;
-            }
+            val[r][x] = csc_int(CHAN, c[0], c[1], c[2]);
         }
+    if (avg) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int x = 0; x < 8; x += 2) {
+            uint32_t m = (val[0][x] + val[0][x + 1] + val[1][x] + val[1][x + 1]) >> 2;
+            val[0][x] = val[0][x + 1] = val[1][x] = val[1][x + 1] = m;
+        }
+    }
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-                pk[r * 2 + h] = val[r][4 * h] | (val[r][4 * h + 1] << 8) | (val[r][4 * h + 2] << 16) |
-                                (val[r][4 * h + 3] << 24);
-    } else {
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t v = 0;
+        for (int h = 0; h < 2; ++h)
+            pk[r * 2 + h] = val[r][4 * h] | (val[r][4 * h + 1] << 8) | (val[r][4 * h + 2] << 16) |
+                            (val[r][4 * h + 3] << 24);
+}
+
+// Edge / unaligned tiles: one sample at a time with mirroring.
+template <int CHAN>
+__device__ __forceinline__ void generic_rowpair(const uint8_t* __restrict__ f, const Geom& g, bool avg,
+                                                uint32_t bx, uint32_t by, uint32_t gq, uint32_t (&pk)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t v = 0;
 #pragma unroll 1
-            for (int j = 0; j < 4; ++j) {
-                int s = i * 4 + j;  // 0..15 within the row pair
-                uint32_t smp = sample_generic_int(f, g, CHAN, avg, bx * 8 + (s & 7), by * 8 + gq * 2 + (s >> 3));
-                v |= smp << (8 * j);
-            }
-            pk[i] = v;
+        for (int j = 0; j < 4; ++j) {
+            int s = i * 4 + j;  // 0..15 within the row pair
+            uint32_t smp = sample_generic_int(f, g, CHAN, avg, bx * 8 + (s & 7), by * 8 + gq * 2 + (s >> 3));
+            v |= smp << (8 * j);
         }
+        pk[i] = v;
     }
 }
 
@@ -171,6 +177,81 @@ struct SlotWriter {  // AC bits of one unit into the lane's LDS slot, layout [wo
         }
     }
 };
+
+// Branch-free bit writer into the lane's LDS slot ([word][lane] layout).  Pending bits are
+// kept left-aligned in a 64-bit accumulator; every put stores the current top word (a
+// later put to the same word overwrites it), so no flush branch and no final flush.
+struct SlotWriterBF {
+    uint32_t* wp;    // address of the word being filled
+    uint64_t acc;    // pending bits, left-aligned
+    uint32_t rem;    // 64 - pending count, in (32, 64]
+    uint32_t w;      // completed words
+    // t = 0 is a no-op provided m == 0; m < 2^t, t <= 31
+    __device__ __forceinline__ void put(uint32_t m, uint32_t t) {
+        rem -= t;
+        acc |= (uint64_t)m << rem;
+        *wp = (uint32_t)(acc >> 32);
+        const bool adv = rem <= 32;
+        acc = adv ? acc << 32 : acc;
+        rem = adv ? rem + 32 : rem;
+        w = adv ? w + 1 : w;
+        wp = adv ? wp + 64 : wp;
+    }
+    // a put that completes a word leaves the remainder unstored until the next put
+    __device__ __forceinline__ void finish() { *wp = (uint32_t)(acc >> 32); }
+    __device__ __forceinline__ uint32_t bits() const { return w * 32 + (64 - rem); }
+    __device__ __forceinline__ uint32_t words() const { return w + (rem < 64 ? 1u : 0u); }
+};
+
+// The unit walk of walk_ac(), restructured for the fused kernel: positions are handled
+// in groups of kWalkGroup; a first pass forms every LUT index (runs only need the zero/non-zero
+// pattern) and issues all LDS lookups, a second pass assembles and appends the symbols
+// without branches (zero coefficients append nothing).  Only the ZRL prefix of a run
+// >= 16 takes a (rare) divergent branch.  Same bits as walk_ac().
+constexpr int kWalkGroup = 8;
+__device__ __forceinline__ bool walk_ac_batched(const uint32_t (&c)[32], const uint32_t* __restrict__ act,
+                                                SlotWriterBF& bw) {
+    bool ok = true;
+    uint32_t run = 0;
+    const uint32_t zrl = act[0xF0], eob = act[0x00];
+#pragma unroll
+    for (int k0 = 1; k0 < 64; k0 += kWalkGroup) {
+        int v[kWalkGroup];
+        uint32_t e[kWalkGroup], sz[kWalkGroup], zc[kWalkGroup];
+#pragma unroll
+        for (int i = 0; i < kWalkGroup; ++i) {
+            const int k = k0 + i;
+            if (k > 63) break;
+            v[i] = (int)(int16_t)((k & 1) ? (c[k >> 1] >> 16) : (c[k >> 1] & 0xffffu));
+            const uint32_t a = (uint32_t)(v[i] < 0 ? -v[i] : v[i]);
+            sz[i] = 32u - (uint32_t)__clz((int)a);
+            const bool nz = v[i] != 0;
+            ok = ok && !(nz && sz[i] > 10u);
+            zc[i] = nz ? (run >> 4) : 0u;
+            e[i] = act[((run & 15u) << 4) | (sz[i] & 15u)];
+            run = nz ? 0u : run + 1u;
+        }
+#pragma unroll
+        for (int i = 0; i < kWalkGroup; ++i) {
+            const int k = k0 + i;
+            if (k > 63) break;
+            const bool nz = v[i] != 0;
+            if (k >= 17 && zc[i]) {  // (15,0) at every 16th zero before a later non-zero
+                for (uint32_t z = 0; z < zc[i]; ++z) bw.put(lut_code(zrl), lut_len(zrl));
+            }
+            const uint32_t len = lut_len(e[i]);
+            ok = ok && !(nz && len == 0u && sz[i] <= 10u);
+            const uint32_t vb = (uint32_t)(v[i] + ((v[i] >> 31) & ((1 << sz[i]) - 1)));
+            const uint32_t m = nz ? ((lut_code(e[i]) << sz[i]) | vb) : 0u;
+            const uint32_t t = nz ? len + sz[i] : 0u;
+            bw.put(m, t & 31u);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: bounded register pressure
+    }
+    bw.put(lut_code(eob), lut_len(eob));  // ALWAYS (quirk Q8)
+    bw.finish();
+    return ok;
+}
 
 // wave-wide inclusive prefix sum
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
@@ -208,86 +289,280 @@ struct WaveArena {
 };
 
 // ----------------------------------------------------------------------------
-// k_screen_encode: persistent single-wave workgroups; one (tile, channel) per
-// iteration.  Lane roles: MFMA phase lane = (n = lane&15: block within a group of
-// 16, gq = lane>>4: row pair / accumulator row group); walk phase lane = block.
+// Unit walk as a loop over NON-ZERO coefficients (the work is proportional to what
+// actually gets coded).  The zig-zag row of the unit lives in LDS; a 64-bit
+// non-zero mask built during quantisation gives the positions (lowest set bit =
+// next coefficient, run = gap to the previous one).  A combined (run, value) LUT
+// returns the complete symbol -- Huffman code and value bits, left-aligned, length
+// in the low five bits -- for |value| <= 31; larger values assemble it from the
+// (run,size) table.  Bits are packed with 32-bit funnel shifts.  LDS reads are
+// software-pipelined two symbols ahead.  Same bits as walk_ac().
 // ----------------------------------------------------------------------------
-template <bool PROBE>
-__global__ void __launch_bounds__(64, 2)
-    k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
-    __shared__ uint32_t s_buf[kSlotWords * 64];  // transpose buffer [64][33] then AC slots [48][64]
-    __shared__ double s_qc[2][64][4];            // {s1, thr1, s2, thr2} per channel type and zig-zag position
-    __shared__ uint32_t s_act[2][256];           // AC code LUTs
-    __shared__ uint32_t s_flag[64];
+constexpr uint32_t kSlotRows = 24;  // words per unit in the LDS slot; larger strings re-walk into global memory
+constexpr uint32_t kLut2Zrl = 15 * 64 + 32;  // (run 15, value 0): ZRL
+constexpr uint32_t kLut2Eob = 1 * 64 + 32;   // spare slot (run 1, value 0): EOB; (run 0, value 0) must stay 0
 
-    const uint32_t lane = threadIdx.x, n = lane & 15, gq = lane >> 4;
-    for (uint32_t i = lane; i < 512; i += 64) {
+// Left-aligned 32-bit bit packer.  e = symbol bits left-aligned | length (<= 27) in bits 4..0.
+// Every put stores the word being filled (a later put to the same word overwrites it).
+template <typename Store>
+struct Packer32 {
+    uint32_t acc = 0;  // pending bits, left-aligned
+    uint32_t n = 0;    // pending count, 0..31
+    uint32_t w = 0;    // completed words
+    Store st;
+    __device__ __forceinline__ explicit Packer32(Store s) : st(s) {}
+    __device__ __forceinline__ void put(uint32_t e) {
+        const uint32_t ml = e & ~31u, t = e & 31u;
+        const uint32_t hi = acc | (ml >> n);
+        const uint32_t lo = __builtin_amdgcn_alignbit(ml, 0u, n);  // ml << (32-n), and 0 when n == 0
+        const uint32_t n2 = n + t;
+        st(w, hi);
+        const bool adv = n2 >= 32u;
+        acc = adv ? lo : hi;
+        w += n2 >> 5;
+        n = n2 & 31u;
+    }
+    __device__ __forceinline__ void finish() { st(w, acc); }
+    __device__ __forceinline__ uint32_t bits() const { return w * 32u + n; }
+    __device__ __forceinline__ uint32_t words() const { return w + (n ? 1u : 0u); }
+};
+
+struct StoreLds {  // [word][lane]; row kSlotRows is a dump row for oversized strings
+    uint32_t* slot;
+    __device__ __forceinline__ void operator()(uint32_t w, uint32_t v) const {
+        slot[(w < kSlotRows ? w : kSlotRows) * 64u] = v;
+    }
+};
+struct StoreGlobal {  // lane-private run of kSlotWordsFull words
+    uint32_t* dst;
+    __device__ __forceinline__ void operator()(uint32_t w, uint32_t v) const {
+        dst[w < kSlotWordsFull - 1 ? w : kSlotWordsFull - 1] = v;
+    }
+};
+
+// Symbol for (run r < 16, value v != 0): LUT2 hit for |v| <= 31, else from the (run,size) table.
+// Returns 0 when the reference has no code for it (quirk Q13).
+__device__ __forceinline__ uint32_t symbol_slow(int v, uint32_t r, const uint32_t* __restrict__ act) {
+    const int size = bit_size(v);
+    if (size > 10) return 0u;
+    const uint32_t a = act[(r << 4) | (uint32_t)size];
+    const uint32_t len = lut_len(a);
+    if (len == 0u) return 0u;
+    const uint32_t t = len + (uint32_t)size;  // <= 27
+    const uint32_t m = (lut_code(a) << size) | value_bits(v, size);
+    return (m << (32u - t)) | t;
+}
+
+struct WalkA {  // stage A result: position of a symbol + its value read in flight
+    uint32_t pos;
+    bool valid;
+    int v;
+};
+struct WalkB {  // stage B result: symbol entry read in flight
+    uint32_t e_fast;
+    uint32_t r;
+    uint32_t zc;
+    int v;
+    bool valid, fast;
+};
+
+// row: this lane's zig-zag row in LDS as int16; mask: non-zero positions 1..63.
+template <typename Store>
+__device__ __forceinline__ bool walk_nonzeros(const int16_t* row, uint64_t mask, const uint32_t* __restrict__ lut2,
+                                              const uint32_t* __restrict__ act, Packer32<Store>& pk) {
+    uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+    uint32_t cnt = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+    uint32_t maxcnt = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)maxcnt, d);
+        maxcnt = o > maxcnt ? o : maxcnt;
+    }
+    maxcnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxcnt);
+    uint32_t prev = 0;
+    bool ok = true;
+
+    auto stageA = [&]() -> WalkA {
+        WalkA a;
+        a.valid = (mlo | mhi) != 0u;
+        const uint32_t plo = (uint32_t)(__ffs((int)mlo) - 1);        // 0xFFFFFFFF when mlo == 0
+        const uint32_t phi = (uint32_t)(__ffs((int)mhi) - 1) + 32u;  // 31 (wrapped) when mhi == 0: only used if mlo == 0 too
+        uint32_t p = plo < phi ? plo : phi;
+        a.pos = a.valid ? p : 0u;
+        // clear the lowest set bit of the 64-bit mask
+        const uint32_t nlo = mlo & (mlo - 1u);
+        const uint32_t nhi = mlo ? mhi : (mhi & (mhi - 1u));
+        mlo = nlo;
+        mhi = nhi;
+        a.v = (int)row[a.pos];
+        return a;
+    };
+    auto stageB = [&](const WalkA& a) -> WalkB {
+        WalkB b;
+        b.valid = a.valid;
+        const uint32_t run = a.pos - prev - 1u;
+        prev = a.valid ? a.pos : prev;
+        b.v = a.valid ? a.v : 0;
+        b.r = a.valid ? (run & 15u) : 0u;
+        b.zc = a.valid ? (run >> 4) : 0u;
+        b.fast = (uint32_t)(b.v + 31) <= 62u;
+        const uint32_t idx = b.fast ? (b.r * 64u + (uint32_t)(b.v + 32)) : 32u;
+        b.e_fast = lut2[idx];
+        return b;
+    };
+    auto stageC = [&](const WalkB& b) {
+        uint32_t e = b.e_fast;
+        if (!b.fast) e = symbol_slow(b.v, b.r, act);
+        ok = ok && !(b.valid && e == 0u);
+        if (b.zc) {  // (15,0) at every 16th zero before a later non-zero
+            const uint32_t z = lut2[kLut2Zrl];
+            for (uint32_t i = 0; i < b.zc; ++i) pk.put(z);
+        }
+        pk.put(e);
+    };
+
+    WalkA a1 = stageA();
+    WalkA a2 = stageA();
+    WalkB b1 = stageB(a1);
+    for (uint32_t i = 0; i < maxcnt; ++i) {
+        WalkA a3 = stageA();
+        WalkB b2 = stageB(a2);
+        stageC(b1);
+        a2 = a3;
+        b1 = b2;
+    }
+    pk.put(lut2[kLut2Eob]);  // ALWAYS (quirk Q8)
+    pk.finish();
+    return ok;
+}
+
+// ----------------------------------------------------------------------------
+// k_screen_encode: 256-thread workgroups = 4 independent persistent waves that share
+// the constant tables in LDS.  One (tile, channel) per wave iteration.  Lane roles:
+// MFMA phase lane = (n = lane&15: block within a group of 16, gq = lane>>4: row pair
+// of the block / row group of the accumulator); walk phase lane = block.
+// ----------------------------------------------------------------------------
+constexpr uint32_t kEncWaves = 4;
+
+template <bool PROBE>
+__global__ void __launch_bounds__(256, 2)
+    k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
+    __shared__ uint32_t s_tbuf_all[kEncWaves][64 * 33];            // zig-zag rows, int16 pairs, stride 33 dwords
+    __shared__ uint32_t s_slot_all[kEncWaves][(kSlotRows + 1) * 64];  // AC strings [word][lane] + dump row
+    __shared__ uint32_t s_mask_all[kEncWaves][2][64];              // non-zero masks (lo, hi)
+    __shared__ uint32_t s_flag_all[kEncWaves][64];
+    __shared__ double s_qc[2][64][4];   // {s1, thr1, s2, thr2} per channel type and zig-zag position
+    __shared__ uint32_t s_act[2][256];  // (run,size) AC tables
+    __shared__ uint32_t s_lut2[2][1024];  // (run,value) symbol tables
+
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
+    uint32_t* s_tbuf = s_tbuf_all[wv];
+    uint32_t* s_slot = s_slot_all[wv];
+    uint32_t* s_mlo = s_mask_all[wv][0];
+    uint32_t* s_mhi = s_mask_all[wv][1];
+    uint32_t* s_flag = s_flag_all[wv];
+    for (uint32_t i = tid; i < 512; i += 256) {
         (&s_qc[0][0][0])[i] = sp.qconst[i];
         (&s_act[0][0])[i] = sp.lut[512 + i];
     }
-    v4i A[4][kScreenLimbs];
+    for (uint32_t i = tid; i < 2048; i += 256) (&s_lut2[0][0])[i] = sp.lut2[i];
+    // A fragments of digits 1..4 stay in registers; digit 0 only matters for the (rare)
+    // second look and is fetched on demand.
+    v4i A[4][kScreenLimbs - 1];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int l = 0; l < kScreenLimbs; ++l) {
+        for (int l = 1; l < kScreenLimbs; ++l) {
             uint4 t = sp.afrag[(mt * kScreenLimbs + l) * 64 + lane];
-            A[mt][l] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+            A[mt][l - 1] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
         }
     __syncthreads();
 
-    WaveArena wa{blockIdx.x * sp.region_words, sp.region_words};
+    // Work distribution.  With a grid that is a multiple of 8 workgroups, the waves of XCD x
+    // (workgroups x, x+8, ...) take the tiles congruent to x mod 8, channel by channel, so
+    // that the three channels of a tile are processed side by side in one XCD and share its
+    // RGB bytes in that L2.  Speed only: any mapping is correct.
+    const uint32_t gwave = blockIdx.x * kEncWaves + wv;   // global wave id
     const uint32_t per_frame = g.tiles * 3;
-    const uint32_t total = per_frame * n_frames;
-    for (uint32_t wt = blockIdx.x; wt < total; wt += gridDim.x) {
-        const uint32_t frame = wt / per_frame, id = wt - frame * per_frame;
-        uint32_t tile, chan;
-        {   // XCD-aware: ids i, i+8, i+16 (same XCD when gridDim.x % 8 == 0) = the 3 channels of one tile
-            uint32_t full = (g.tiles / 8) * 24;
-            if (id < full) {
-                uint32_t grp = id / 24, w = id % 24;
-                tile = grp * 8 + (w & 7);
-                chan = w >> 3;
-            } else {
-                uint32_t r = id - full;
-                tile = (g.tiles / 8) * 8 + r / 3;
-                chan = r % 3;
-            }
+    const bool xcd_map = (gridDim.x % 8u) == 0u;
+    const uint32_t xcd = blockIdx.x % 8u;
+    const uint32_t local = (blockIdx.x / 8u) * kEncWaves + wv;       // index of this wave inside its XCD
+    const uint32_t local_n = (gridDim.x / 8u) * kEncWaves;           // waves per XCD
+    const uint32_t tiles_x = xcd_map ? (g.tiles + 7u - xcd) / 8u : 0u;  // tiles this XCD owns per frame
+    const uint32_t pairs_total = xcd_map ? tiles_x * 3u * n_frames : per_frame * n_frames;
+    const uint32_t pstart = xcd_map ? local : gwave;
+    const uint32_t pstep = xcd_map ? local_n : gridDim.x * kEncWaves;
+
+    WaveArena wa{gwave * sp.region_words, sp.region_words};
+    for (uint32_t p = pstart; p < pairs_total; p += pstep) {
+        uint32_t frame, tile, chan;
+        if (xcd_map) {
+            const uint32_t pf = tiles_x * 3u;
+            frame = p / pf;
+            const uint32_t q = p - frame * pf;
+            tile = (q / 3u) * 8u + xcd;
+            chan = q % 3u;
+        } else {
+            frame = p / per_frame;
+            const uint32_t q = p - frame * per_frame;
+            tile = q / 3u;
+            chan = q % 3u;
         }
         const uint32_t ct = chan ? 1u : 0u;
         const uint8_t* f = rgb + (size_t)frame * g.frame_stride;
         const bool avg = (chan != 0) && (g.flags & 1u);
         const size_t us_base = (((size_t)frame * g.tiles + tile) * 3 + chan) * 64;
 
-        // are all 64 blocks of this tile inside the image (no mirror padding)?
+        // block coordinates of this lane's four blocks (16j + n), and whether the whole tile
+        // lies inside the image (no mirror padding)
+        uint32_t bxs[4], bys[4];
         bool interior = true;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint32_t b = tile * 64 + 16 * j + n;
-            b = b < g.N ? b : g.N - 1;
+        {
+            uint32_t b = tile * 64 + n;
             uint32_t by = b / g.nbx, bx = b - by * g.nbx;
-            interior = interior && (bx * 8 + 8 <= g.W) && (by * 8 + 8 <= g.H);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t bb = tile * 64 + 16 * j + n;
+                if (bb >= g.N) {  // past the last block: any valid block will do, the lane is masked later
+                    bx = g.nbx - 1;
+                    by = g.N / g.nbx - 1;
+                }
+                bxs[j] = bx;
+                bys[j] = by;
+                interior = interior && (bx * 8 + 8 <= g.W) && (by * 8 + 8 <= g.H);
+                bx += 16;
+                while (bx >= g.nbx) {
+                    bx -= g.nbx;
+                    ++by;
+                }
+            }
         }
         const bool fast = g.fast_rows && __all(interior);
 
         s_flag[lane] = 0;
+        s_mlo[lane] = 0;
+        s_mhi[lane] = 0;
         __builtin_amdgcn_wave_barrier();
 
-#pragma unroll 1
+        // raw RGB of unit-tile j+1 is fetched while unit-tile j is processed
+        uint32_t raw[12];
+        if (fast) load_raw_rowpair(f, g, bxs[0], bys[0], gq, raw);
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-            uint32_t b = tile * 64 + 16 * j + n;
-            b = b < g.N ? b : g.N - 1;
-            const uint32_t by = b / g.nbx, bx = b - by * g.nbx;
-            uint32_t pk[4] = {b, by, bx, gq};
-            if (g.flags & 0x400u) {
-            } else if (chan == 0) {
-                if (fast) load_rowpair<0, true>(f, g, false, bx, by, gq, pk);
-                else load_rowpair<0, false>(f, g, false, bx, by, gq, pk);
-            } else if (chan == 1) {
-                if (fast) load_rowpair<1, true>(f, g, avg, bx, by, gq, pk);
-                else load_rowpair<1, false>(f, g, avg, bx, by, gq, pk);
+            const uint32_t bx = bxs[j], by = bys[j];
+            uint32_t pk[4];
+            if (fast) {
+                uint32_t cur[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) cur[i] = raw[i];
+                if (j < 3) load_raw_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, raw);
+                if (chan == 0) convert_rowpair<0>(cur, false, pk);
+                else if (chan == 1) convert_rowpair<1>(cur, avg, pk);
+                else convert_rowpair<2>(cur, avg, pk);
             } else {
-                if (fast) load_rowpair<2, true>(f, g, avg, bx, by, gq, pk);
-                else load_rowpair<2, false>(f, g, avg, bx, by, gq, pk);
+                if (chan == 0) generic_rowpair<0>(f, g, false, bx, by, gq, pk);
+                else if (chan == 1) generic_rowpair<1>(f, g, avg, bx, by, gq, pk);
+                else generic_rowpair<2>(f, g, avg, bx, by, gq, pk);
             }
             if constexpr (PROBE) {
                 if (sp.samples && tile * 64 + 16 * j + n < g.N) {
@@ -314,50 +589,64 @@ __global__ void __launch_bounds__(64, 2)
             const int q0 = (int)__builtin_round(c0 / sp.qd[ct * 64]);
 
             bool amb = false;
-            if (g.flags & 0x200u) {
-                s_buf[(16 * j + n) * 33 + gq] = pk[0] ^ pk[1] ^ pk[2] ^ pk[3] ^ ssum;
-                continue;
-            }
+            uint32_t nzlo = 0, nzhi = 0;  // this lane's part of the unit's non-zero mask
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                v4i acc[kScreenLimbs];
+                v4i acc[kScreenLimbs - 1];
 #pragma unroll
-                for (int l = 0; l < kScreenLimbs; ++l)
+                for (int l = 0; l < kScreenLimbs - 1; ++l)
                     acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mt][l], B, v4i{0, 0, 0, 0}, 0, 0, 0);
                 int q[4];
+                double y1s[4];
+                bool a1[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int hi = acc[4][r] * 256 + acc[3][r];
-                    const int mid = acc[2][r] * 256 + acc[1][r];
+                    const int hi = acc[3][r] * 256 + acc[2][r];
+                    const int mid = acc[1][r] * 256 + acc[0][r];
                     const double y1 = (double)hi * 65536.0 + (double)mid;  // exact
                     const double* qc = &s_qc[ct][16 * mt + 4 * gq + r][0];
-                    double z = y1 * qc[0];
-                    double t = __builtin_fabs(z) + 0.5;
-                    double fr = t - __builtin_floor(t);
-                    int nn = (int)t;
-                    bool a = !(__builtin_fabs(fr - 0.5) < qc[1]);
-                    if (a) {  // second look with the least significant digit included
-                        const double y2 = y1 * 256.0 + (double)acc[0][r];  // exact
-                        z = y2 * qc[2];
-                        t = __builtin_fabs(z) + 0.5;
-                        fr = t - __builtin_floor(t);
-                        nn = (int)t;
-                        a = !(__builtin_fabs(fr - 0.5) < qc[3]);
-                    }
+                    const double z = y1 * qc[0];
+                    const double t = __builtin_fabs(z) + 0.5;
+                    const double fr = t - __builtin_floor(t);
+                    const int nn = (int)t;
+                    a1[r] = !(__builtin_fabs(fr - 0.5) < qc[1]);
                     q[r] = z < 0.0 ? -nn : nn;
-                    if (mt == 0 && r == 0) {
-                        if (gq == 0) {
-                            q[r] = q0;
-                            a = false;
+                    y1s[r] = y1;
+                    if (mt == 0 && r == 0 && gq == 0) {
+                        q[r] = q0;  // coefficient 0 is formed exactly
+                        a1[r] = false;
+                    }
+                }
+                if (__any(a1[0] || a1[1] || a1[2] || a1[3])) {
+                    // second look with the least significant digit included (wave-uniform, rare)
+                    uint4 t0 = sp.afrag[(mt * kScreenLimbs) * 64 + lane];
+                    v4i acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w}, B,
+                                                                     v4i{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (a1[r]) {
+                            const double* qc = &s_qc[ct][16 * mt + 4 * gq + r][0];
+                            const double y2 = y1s[r] * 256.0 + (double)acc0[r];  // exact
+                            const double z = y2 * qc[2];
+                            const double t = __builtin_fabs(z) + 0.5;
+                            const double fr = t - __builtin_floor(t);
+                            const int nn = (int)t;
+                            q[r] = z < 0.0 ? -nn : nn;
+                            amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
                         }
                     }
-                    amb = amb || a;
                 }
-                // zig-zag positions 16mt+4gq .. +3 of unit 16j+n -> transpose buffer
-                uint32_t* row = &s_buf[(16 * j + n) * 33 + 8 * mt + 2 * gq];
+                // zig-zag positions 16mt+4gq .. +3 of unit 16j+n -> transpose buffer + non-zero bits
+                uint32_t* row = &s_tbuf[(16 * j + n) * 33 + 8 * mt + 2 * gq];
                 row[0] = ((uint32_t)q[0] & 0xffffu) | ((uint32_t)q[1] << 16);
                 row[1] = ((uint32_t)q[2] & 0xffffu) | ((uint32_t)q[3] << 16);
+                const uint32_t nib = (q[0] != 0 ? 1u : 0u) | (q[1] != 0 ? 2u : 0u) | (q[2] != 0 ? 4u : 0u) |
+                                     (q[3] != 0 ? 8u : 0u);
+                if (mt < 2) nzlo |= nib << (16 * mt);
+                else nzhi |= nib << (16 * (mt - 2));
             }
+            atomicOr(&s_mlo[16 * j + n], nzlo << (4 * gq));
+            atomicOr(&s_mhi[16 * j + n], nzhi << (4 * gq));
             if (amb) s_flag[16 * j + n] = 1;
         }
         __builtin_amdgcn_wave_barrier();
@@ -365,47 +654,44 @@ __global__ void __launch_bounds__(64, 2)
         // ---- walk phase: lane = block
         const uint32_t b = tile * 64 + lane;
         const bool active = b < g.N;
-        uint32_t c[32];
-#pragma unroll
-        for (int p = 0; p < 32; ++p) c[p] = s_buf[lane * 33 + p];
         bool flagged = s_flag[lane] != 0;
-        __builtin_amdgcn_wave_barrier();  // s_buf is reused as the slot array below
+        const int16_t* row16 = reinterpret_cast<const int16_t*>(&s_tbuf[lane * 33]);
+        const uint64_t mask = ((uint64_t)s_mhi[lane] << 32 | s_mlo[lane]) & ~1ull;
+        const int dc = (int)row16[0];
 
         if constexpr (PROBE) {
             uint32_t* dst = sp.coefs + us_base / 64 * 2048 + lane;
 #pragma unroll
-            for (int p = 0; p < 32; ++p) dst[p * 64] = active ? c[p] : 0u;
+            for (int pp = 0; pp < 32; ++pp) dst[pp * 64] = active ? s_tbuf[lane * 33 + pp] : 0u;
         }
 
-        SlotWriter sw{&s_buf[lane], kSlotWords, 0, 0, 0, 0};
-        auto put = [&](uint32_t code, uint32_t len) { sw.put(code, len); };
-        bool ok = true;
-        if (g.flags & 0x100u) {
-            uint32_t x = 0;
-#pragma unroll
-            for (int p = 0; p < 32; ++p) x ^= c[p];
-            sw.put(x & 0xffffu, 16);
-        } else {
-            ok = walk_ac(c, s_act[ct], put);
-        }
-        const uint32_t aclen = sw.bits;
-        sw.flush();
-        if (sw.w > kSlotWords) flagged = true;  // oversized AC string: k_fixup has full-size slots
+        Packer32<StoreLds> pkr(StoreLds{&s_slot[lane]});
+        bool ok = walk_nonzeros(row16, mask, s_lut2[ct], s_act[ct], pkr);
+        const uint32_t aclen = pkr.bits();
+        uint32_t nw = pkr.words();
+        const bool oversize = nw > kSlotRows;
         if (!active) flagged = false;
         if (!ok && active && !flagged) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY (decided coefficients only)
+        if (!active || flagged) nw = 0;
 
-        const uint32_t nw = (active && !flagged) ? sw.w : 0u;
-        const uint32_t incl = wave_incl_scan(nw, lane);
+        // arena space: regular strings back to back; oversized ones get a full-size private run
+        const uint32_t need = oversize && nw ? kSlotWordsFull : nw;
+        const uint32_t incl = wave_incl_scan(need, lane);
         const uint32_t base = wa.take(sp, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), lane);
-        const uint32_t off = base + incl - nw;
+        const uint32_t off = base + incl - need;
         const bool fits = base != 0xFFFFFFFFu;
         if (!fits) {
             if (lane == 0) atomicOr(sp.status, 2u);  // MI355_E_CAPACITY
         } else {
-            for (uint32_t w = 0; __any(w < nw); ++w)
-                if (w < nw) sp.arena[off + w] = s_buf[w * 64 + lane];
+            for (uint32_t w = 0; __any(w < nw && !oversize); ++w)
+                if (w < nw && !oversize) sp.arena[off + w] = s_slot[w * 64 + lane];
+            if (__any(oversize && nw)) {  // rare: string longer than the LDS slot: walk again, straight to memory
+                if (oversize && nw) {
+                    Packer32<StoreGlobal> pg(StoreGlobal{sp.arena + off});
+                    (void)walk_nonzeros(row16, mask, s_lut2[ct], s_act[ct], pg);
+                }
+            }
         }
-        const int dc = (int)(int16_t)(c[0] & 0xffffu);
         sp.meta[us_base + lane] = make_uint2(off, active ? ((aclen << 16) | ((uint32_t)dc & 0xffffu)) : 0u);
         if (flagged) {
             uint32_t k = atomicAdd(sp.counters + 1, 1u);
@@ -619,19 +905,23 @@ __global__ void __launch_bounds__(192)
 // ----------------------------------------------------------------------------
 // launchers
 // ----------------------------------------------------------------------------
+// Number of persistent WAVES (4 per workgroup).  Full groups of 8 workgroups whenever the
+// work allows, so that the XCD-aware tile mapping applies.
 uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves) {
     uint32_t total = g.tiles * 3 * n_frames;
-    uint32_t grid = total < max_waves ? total : max_waves;
-    if (grid > 8) grid &= ~7u;  // keep blockIdx.x % 8 stable across the grid-stride loop
-    return grid;
+    uint32_t wgs = (total + kEncWaves - 1) / kEncWaves;
+    uint32_t max_wgs = max_waves / kEncWaves ? max_waves / kEncWaves : 1;
+    if (wgs > max_wgs) wgs = max_wgs;
+    if (wgs >= 8) wgs &= ~7u;
+    return wgs * kEncWaves;
 }
 hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,
                                 bool probe, uint32_t grid_waves, hipStream_t s) {
-    uint32_t grid = screen_grid(g, n_frames, grid_waves);
+    uint32_t grid = screen_grid(g, n_frames, grid_waves) / kEncWaves;
     if (probe)
-        hipLaunchKernelGGL((k_screen_encode<true>), dim3(grid), dim3(64), 0, s, g, n_frames, rgb, sp);
+        hipLaunchKernelGGL((k_screen_encode<true>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
     else
-        hipLaunchKernelGGL((k_screen_encode<false>), dim3(grid), dim3(64), 0, s, g, n_frames, rgb, sp);
+        hipLaunchKernelGGL((k_screen_encode<false>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
     return hipGetLastError();
 }
 hipError_t launch_fixup(const Geom& g, const uint8_t* rgb, const ScreenParams& sp, bool probe,

@@ -134,6 +134,7 @@ struct mi355_jpeg_ctx {
     // screened (integer-MFMA) pipeline
     uint4* d_afrag = nullptr;       // MFMA A fragments of the fixed-point map (static)
     double* d_qconst = nullptr;     // [2][64][4] accept thresholds for the current tables
+    uint32_t* d_lut2 = nullptr;     // [2][16][64] whole AC symbols for |value| <= 31
     uint32_t* d_counters = nullptr; // [0] arena words, [1] fix-up list length
     uint2* d_meta = nullptr;
     size_t meta_cap = 0;
@@ -203,6 +204,28 @@ int upload_tables(mi355_jpeg_ctx* c) {
             qc[ct][R][3] = tau2 < 0.5 ? 0.5 - tau2 : -1.0;
         }
     HIP_TRY(hipMemcpy(c->d_qconst, qc, sizeof qc, hipMemcpyHostToDevice));
+    // Whole-symbol tables of the screened pipeline's unit walk: for run r and value v (|v| <= 31)
+    // the Huffman code of (r, size(v)) followed by v's value bits, left-aligned in 32 bits, with
+    // the total length in bits 4..0; 0 = the reference has no code.  (15, 0) = ZRL; the spare
+    // slot (1, 0) carries EOB; (0, 0) stays 0 (a no-op for exhausted lanes).
+    std::vector<uint32_t> lut2(2 * 1024, 0u);
+    for (int ct = 0; ct < 2; ++ct) {
+        const mi355_huff_table& t = c->huff[2 + ct];
+        auto entry = [&](uint32_t bits, int len) -> uint32_t { return len ? ((bits << (32 - len)) | (uint32_t)len) : 0u; };
+        for (int r = 0; r < 16; ++r)
+            for (int v = -31; v <= 31; ++v) {
+                if (v == 0) continue;
+                int a = v < 0 ? -v : v, size = 0;
+                while (a) ++size, a >>= 1;
+                int rs = (r << 4) | size;
+                if (!t.len[rs]) continue;
+                uint32_t vb = (uint32_t)(v < 0 ? v + (1 << size) - 1 : v);
+                lut2[ct * 1024 + r * 64 + v + 32] = entry((t.code[rs] << size) | vb, t.len[rs] + size);
+            }
+        lut2[ct * 1024 + 15 * 64 + 32] = entry(t.code[0xF0], t.len[0xF0]);
+        lut2[ct * 1024 + 1 * 64 + 32] = entry(t.code[0x00], t.len[0x00]);
+    }
+    HIP_TRY(hipMemcpy(c->d_lut2, lut2.data(), lut2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return MI355_OK;
 }
 
@@ -285,6 +308,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.qconst = c->d_qconst;
     sp.qd = c->d_q;
     sp.lut = c->d_lut;
+    sp.lut2 = c->d_lut2;
     sp.meta = c->d_meta;
     sp.arena = c->d_arena;
     sp.arena_words = (uint32_t)(arena_words > 0xFFFFFFFFull ? 0xFFFFFFFFull : arena_words);
@@ -356,7 +380,9 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
 int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t* d_rgb, uint8_t* d_out,
                  size_t out_stride, uint64_t* d_bits, hipStream_t s) {
     // AC blobs are word aligned per unit: at most total_bits/32 + one word per unit
-    ArenaPlan plan = plan_arena(c, g, n_frames, (size_t)n_frames * (out_stride / 4 + (size_t)g.N * 3));
+    // AC strings are word aligned per unit (<= bits/32 + 1 words); strings longer than the LDS
+    // slot (24 words) get a full 54-word run, i.e. at most 54/24 of their own size
+    ArenaPlan plan = plan_arena(c, g, n_frames, (size_t)n_frames * (out_stride / 4 * 9 / 4 + (size_t)g.N * 3 + 64));
     if (plan.total_words > 0xFFFFFFFFull) return MI355_E_ARG;  // 32-bit word offsets: split the batch
     int e;
     if ((e = ensure_screen_workspace(c, g, n_frames, plan.total_words))) return e;
@@ -448,6 +474,7 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
         hipMalloc((void**)&c->d_status, sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_afrag, (size_t)4 * kScreenLimbs * 64 * 16) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&c->d_lut2, 2048 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_counters, 2 * sizeof(uint32_t)) != hipSuccess)
         e = MI355_E_ALLOC;
     if (!e) e = hip_err(hipMemset(c->d_status, 0, sizeof(uint32_t)));
@@ -467,7 +494,7 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
                     c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
-                    c->d_counters, c->d_meta,     c->d_arena,  c->d_fixlist};
+                    c->d_counters, c->d_meta,     c->d_arena,  c->d_fixlist, c->d_lut2};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& es : c->ev_pool)

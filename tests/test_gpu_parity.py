@@ -199,6 +199,25 @@ def test_screened_transform_forced_fixups(jpeg, monkeypatch, scale):
     e2.close()
 
 
+def test_oversized_ac_strings(jpeg, enc):
+    """Very high quality on noise: units whose AC bit string exceeds the 24-word LDS slot
+    of the fused kernel take the re-walk-to-memory path (and the tile may exceed the merge
+    kernel's LDS window)."""
+    rgb = ol.lcg_frame(256, 128, 6)
+    seen_big = False
+    for q in (95, 97, 98):
+        ql, qc = set_quality(enc, q)
+        try:
+            o = ol.oracle_encode(rgb, ql, qc, False, KEEP)
+        except RuntimeError:
+            continue
+        seen_big |= int(o.unit_bits.max()) > 24 * 32 + 30
+        assert np.array_equal(enc.probe_unit_bits(rgb, 0), o.unit_bits), q
+        bits, nb = enc.encode_scan(rgb, 0)
+        assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits), q
+    assert seen_big
+
+
 def test_exhaustive_colour_conversion_on_gpu(jpeg, enc):
     """All 2^24 RGB triples through the product's integer-exact CSC (the screened
     pipeline's sample stage) against the reference's output hash."""
