@@ -37,6 +37,7 @@ struct ScreenParams {
     uint32_t* fixlist;      // unit slot indices to recompute exactly
     uint32_t fixcap;
     uint32_t* status;
+    uint32_t* tile_bits;    // [frame][tile] bit totals, accumulated with atomics (zero on entry)
     uint32_t* coefs;        // probe output (tiled coefficient layout) or nullptr
     uint8_t* samples;       // probe output (padded YCbCr image, interleaved) or nullptr
 };
@@ -50,7 +51,7 @@ hipError_t launch_fixup(const Geom& g, const uint8_t* rgb, const ScreenParams& s
 hipError_t launch_meta_sizes(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* lut,
                              uint32_t* unit_off, uint32_t* tile_bits, uint32_t* status, hipStream_t s);
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,
-                        const uint32_t* lut, const uint32_t* unit_off, const uint64_t* tile_off,
+                        const uint32_t* lut, const uint64_t* tile_off,
                         uint8_t* out, uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,
                         hipStream_t s);
 
@@ -60,10 +61,10 @@ hipError_t launch_probe_samples(const Geom& g, const uint8_t* rgb, uint8_t* samp
 hipError_t launch_unit_sizes(const Geom& g, uint32_t n_frames, const uint32_t* coefs,
                              const uint32_t* lut, uint32_t* unit_off, uint32_t* tile_bits,
                              uint32_t* status, hipStream_t s);
-hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, const uint32_t* tile_bits,
+hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, uint32_t* tile_bits,
                             uint64_t* tile_off, uint8_t* out, uint64_t out_stride,
                             uint64_t* frame_bits, uint32_t* status, uint32_t* reset_counters,
-                            hipStream_t s);
+                            bool rearm_tiles, hipStream_t s);
 hipError_t launch_emit(const Geom& g, uint32_t n_frames, const uint32_t* coefs, const uint32_t* lut,
                        const uint32_t* unit_off, const uint64_t* tile_off, uint8_t* out,
                        uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,

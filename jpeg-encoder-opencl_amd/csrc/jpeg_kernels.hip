@@ -174,47 +174,47 @@ __global__ void __launch_bounds__(192)
 }
 
 // ----------------------------------------------------------------------------
-// k_tile_scan: one workgroup per frame; exclusive 64-bit scan of the tile sums.
-// Also zeroes every output word that two tiles share (k_emit ORs into those),
-// writes the frame's bit count and checks the caller's capacity.
+// k_tile_scan: one 1024-thread workgroup per frame; exclusive 64-bit scan of the tile
+// sums (each thread owns a contiguous chunk of tiles).  Also zeroes every output word
+// that two tiles share (the emit/merge kernels OR into those), writes the frame's bit
+// count, checks the caller's capacity and -- for the screened pipeline, whose encode
+// kernel accumulates the tile sums with atomics -- re-arms the sums and counters.
 // ----------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-    k_tile_scan(Geom g, const uint32_t* __restrict__ tile_bits, uint64_t* __restrict__ tile_off,
+__global__ void __launch_bounds__(1024)
+    k_tile_scan(Geom g, uint32_t* __restrict__ tile_bits, uint64_t* __restrict__ tile_off,
                 uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ frame_bits,
-                uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters) {
-    __shared__ uint64_t s_wave[4];
-    __shared__ uint64_t s_carry;
+                uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters, uint32_t rearm_tiles) {
+    __shared__ uint64_t s_wave[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t frame = blockIdx.x;
-    const uint32_t* tb = tile_bits + (size_t)frame * g.tiles;
+    uint32_t* tb = tile_bits + (size_t)frame * g.tiles;
     uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
     uint32_t* outw = reinterpret_cast<uint32_t*>(out + (size_t)frame * out_stride);
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < g.tiles; base += 256) {
-        uint32_t i = base + tid;
-        uint64_t v = i < g.tiles ? tb[i] : 0, incl = v;
+    const uint32_t per = (g.tiles + 1023u) / 1024u;
+    const uint32_t lo = tid * per < g.tiles ? tid * per : g.tiles;
+    const uint32_t hi = lo + per < g.tiles ? lo + per : g.tiles;
+    uint64_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += tb[i];
+    uint64_t incl = sum;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint64_t n = __shfl_up(incl, d);
-            if ((int)lane >= d) incl += n;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint64_t pre = s_carry;
-        for (uint32_t w = 0; w < wave; ++w) pre += s_wave[w];
-        uint64_t excl = pre + incl - v;
-        if (i < g.tiles) {
-            to[i] = excl;
-            // word shared with the previous tile: both sides OR into it
-            if (i > 0 && (excl & 31) && (excl >> 5) * 4 + 4 <= out_stride) outw[excl >> 5] = 0;
-        }
-        __syncthreads();
-        if (tid == 255) s_carry = pre + incl;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t n = __shfl_up(incl, d);
+        if ((int)lane >= d) incl += n;
     }
-    if (tid == 0) {
-        uint64_t total = s_carry;
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t pre = 0;
+    for (uint32_t w = 0; w < wave; ++w) pre += s_wave[w];
+    uint64_t run = pre + incl - sum;  // exclusive offset of this thread's first tile
+    for (uint32_t i = lo; i < hi; ++i) {
+        to[i] = run;
+        // word shared with the previous tile: both sides OR into it
+        if (i > 0 && (run & 31) && (run >> 5) * 4 + 4 <= out_stride) outw[run >> 5] = 0;
+        run += tb[i];
+        if (rearm_tiles) tb[i] = 0;
+    }
+    if (tid == 1023) {
+        const uint64_t total = pre + incl;
         to[g.tiles] = total;
         frame_bits[frame] = total;
         if (((total + 31) >> 5) * 4 > out_stride) atomicOr(status, 2u);  // MI355_E_CAPACITY
@@ -363,12 +363,12 @@ hipError_t launch_unit_sizes(const Geom& g, uint32_t n_frames, const uint32_t* c
                        tile_bits, status);
     return hipGetLastError();
 }
-hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, const uint32_t* tile_bits,
+hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, uint32_t* tile_bits,
                             uint64_t* tile_off, uint8_t* out, uint64_t out_stride,
                             uint64_t* frame_bits, uint32_t* status, uint32_t* reset_counters,
-                            hipStream_t s) {
-    hipLaunchKernelGGL(k_tile_scan, dim3(n_frames), dim3(256), 0, s, g, tile_bits, tile_off, out,
-                       out_stride, frame_bits, status, reset_counters);
+                            bool rearm_tiles, hipStream_t s) {
+    hipLaunchKernelGGL(k_tile_scan, dim3(n_frames), dim3(1024), 0, s, g, tile_bits, tile_off, out,
+                       out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u);
     return hipGetLastError();
 }
 hipError_t launch_emit(const Geom& g, uint32_t n_frames, const uint32_t* coefs, const uint32_t* lut,

@@ -253,6 +253,8 @@ __device__ __forceinline__ bool walk_ac_batched(const uint32_t (&c)[32], const u
     return ok;
 }
 
+__device__ __forceinline__ int meta_dc(uint32_t y) { return (int)(int16_t)(y & 0xffffu); }
+
 // wave-wide inclusive prefix sum
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
 #pragma unroll
@@ -454,6 +456,7 @@ __global__ void __launch_bounds__(256, 2)
     __shared__ double s_qc[2][64][4];   // {s1, thr1, s2, thr2} per channel type and zig-zag position
     __shared__ uint32_t s_act[2][256];  // (run,size) AC tables
     __shared__ uint32_t s_lut2[2][1024];  // (run,value) symbol tables
+    __shared__ uint32_t s_dc[2][16];      // DC tables
 
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
     uint32_t* s_tbuf = s_tbuf_all[wv];
@@ -466,6 +469,7 @@ __global__ void __launch_bounds__(256, 2)
         (&s_act[0][0])[i] = sp.lut[512 + i];
     }
     for (uint32_t i = tid; i < 2048; i += 256) (&s_lut2[0][0])[i] = sp.lut2[i];
+    if (tid < 32) s_dc[tid >> 4][tid & 15] = sp.lut[(tid >> 4) * 256 + (tid & 15)];
     // A fragments of digits 1..4 stay in registers; digit 0 only matters for the (rare)
     // second look and is fetched on demand.
     v4i A[4][kScreenLimbs - 1];
@@ -674,6 +678,34 @@ __global__ void __launch_bounds__(256, 2)
         if (!ok && active && !flagged) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY (decided coefficients only)
         if (!active || flagged) nw = 0;
 
+        // Total bits of the unit = DC symbol + AC string.  The DC difference needs the previous
+        // block of the same channel: the neighbouring lane, or for lane 0 the last block of the
+        // previous tile, whose DC (always the exact fl(sum*SCALE_00)/Q0 form) is recomputed here
+        // from its 64 samples, one per lane.  Tile sums are accumulated with one atomic per wave
+        // (units left to k_fixup add themselves there).
+        {
+            int pred0 = 0;
+            if (tile > 0) {
+                const uint32_t pb = tile * 64 - 1;
+                const uint32_t pby = pb / g.nbx, pbx = pb - pby * g.nbx;
+                uint32_t sm = sample_generic_int(f, g, (int)chan, avg, pbx * 8 + (lane & 7), pby * 8 + (lane >> 3));
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) sm += (uint32_t)__shfl_xor((int)sm, d);
+                const double pc0 = (double)((int)sm - 8192) * kScale00;
+                pred0 = (int)__builtin_round(pc0 / sp.qd[ct * 64]);
+            }
+            int pred = __shfl_up(dc, 1);
+            if (lane == 0) pred = pred0;
+            uint32_t ubits = aclen;
+            auto count = [&](uint32_t, uint32_t len) { ubits += len; };
+            const bool dc_ok = put_dc(dc - pred, s_dc[ct], count);
+            if (!dc_ok && active) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
+            if (!active || flagged) ubits = 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) ubits += (uint32_t)__shfl_xor((int)ubits, d);
+            if (lane == 0 && ubits) atomicAdd(&sp.tile_bits[(size_t)frame * g.tiles + tile], ubits);
+        }
+
         // arena space: regular strings back to back; oversized ones get a full-size private run
         const uint32_t need = oversize && nw ? kSlotWordsFull : nw;
         const uint32_t incl = wave_incl_scan(need, lane);
@@ -710,8 +742,10 @@ __global__ void __launch_bounds__(64)
     __shared__ uint32_t s_slot[kSlotWordsFull * 64];
     __shared__ uint32_t s_act[2][256];
     __shared__ uint32_t s_smp[16 * 64];
+    __shared__ uint32_t s_dcf[2][16];
     const uint32_t lane = threadIdx.x;
     for (uint32_t i = lane; i < 512; i += 64) (&s_act[0][0])[i] = sp.lut[512 + i];
+    if (lane < 32) s_dcf[lane >> 4][lane & 15] = sp.lut[(lane >> 4) * 256 + (lane & 15)];
     __syncthreads();
     uint32_t count = sp.counters[1];
     if (count > sp.fixcap) count = sp.fixcap;
@@ -772,6 +806,14 @@ __global__ void __launch_bounds__(64)
             }
             const int dc = (int)(int16_t)(c[0] & 0xffffu);
             sp.meta[us] = make_uint2(off, (aclen << 16) | ((uint32_t)dc & 0xffffu));
+            // this unit's share of the tile sum (k_screen_encode left it out); every DC in meta is exact
+            int pred = 0;
+            if (ul > 0) pred = meta_dc(sp.meta[us - 1].y);
+            else if (tile > 0) pred = meta_dc(sp.meta[(((size_t)frame * g.tiles + tile - 1) * 3 + chan) * 64 + 63].y);
+            uint32_t ubits = aclen;
+            auto count = [&](uint32_t, uint32_t len) { ubits += len; };
+            if (!put_dc(dc - pred, s_dcf[chan ? 1 : 0], count)) atomicOr(sp.status, 1u);
+            atomicAdd(&sp.tile_bits[(size_t)frame * g.tiles + tile], ubits);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -781,8 +823,6 @@ __global__ void __launch_bounds__(64)
 // k_meta_sizes: workgroup = tile (wave = channel, lane = block): total bits per
 // unit = DC symbol + AC string; tile-local exclusive offsets + tile sums.
 // ----------------------------------------------------------------------------
-__device__ __forceinline__ int meta_dc(uint32_t y) { return (int)(int16_t)(y & 0xffffu); }
-
 __device__ __forceinline__ int meta_pred(const uint2* __restrict__ meta, size_t frame_tile0, uint32_t tile,
                                          uint32_t chan, uint32_t lane, int own_dc) {
     int prev = __shfl_up(own_dc, 1);
@@ -834,25 +874,13 @@ __global__ void __launch_bounds__(192)
 // ----------------------------------------------------------------------------
 // k_merge: like k_emit, but the AC bits come ready-made from the arena.
 // ----------------------------------------------------------------------------
-template <typename Writer>
-__device__ __forceinline__ void merge_unit(Writer& bw, int diff, const uint32_t* dct,
-                                           const uint32_t* __restrict__ arena, uint32_t off, uint32_t aclen) {
-    auto put = [&](uint32_t code, uint32_t len) { bw.put(code, len); };
-    put_dc(diff, dct, put);
-    for (uint32_t done = 0; done < aclen; done += 32) {
-        uint32_t w = arena[off + (done >> 5)];
-        uint32_t len = aclen - done < 32 ? aclen - done : 32;
-        bw.put(w >> (32 - len), len);
-    }
-    bw.flush();
-}
-
 __global__ void __launch_bounds__(192)
     k_merge(Geom g, const uint2* __restrict__ meta, const uint32_t* __restrict__ arena,
-            const uint32_t* __restrict__ lut, const uint32_t* __restrict__ unit_off,
-            const uint64_t* __restrict__ tile_off, uint8_t* __restrict__ out, uint64_t out_stride,
-            const uint32_t* __restrict__ status, uint32_t lds_words_limit) {
+            const uint32_t* __restrict__ lut, const uint64_t* __restrict__ tile_off,
+            uint8_t* __restrict__ out, uint64_t out_stride, const uint32_t* __restrict__ status,
+            uint32_t lds_words_limit) {
     __shared__ uint32_t s_dc[2][16];
+    __shared__ uint32_t s_bits[192];
     __shared__ uint32_t s_words[kEmitLdsWords];
     const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
     const uint32_t tile = blockIdx.x, frame = blockIdx.y;
@@ -874,19 +902,58 @@ __global__ void __launch_bounds__(192)
             if (!shared) __hip_atomic_store(&outw[w0 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    // this unit: DC, AC length, arena offset; the first words of its AC string are fetched now
+    const bool active = tile * 64 + lane < g.N;
+    const uint2 m = meta[((ft0 + tile) * 3 + chan) * 64 + lane];
+    const int dc = meta_dc(m.y);
+    const uint32_t aclen = active ? (m.y >> 16) : 0u;
+    const int pred = meta_pred(meta, ft0, tile, chan, lane, dc);
+    uint32_t pre[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[i] = (uint32_t)i * 32u < aclen ? arena[m.x + i] : 0u;
     __syncthreads();
-    if (tile * 64 + lane < g.N) {
-        const uint2 m = meta[((ft0 + tile) * 3 + chan) * 64 + lane];
-        const int dc = meta_dc(m.y);
-        const int pred = meta_pred(meta, ft0, tile, chan, lane, dc);
-        const uint32_t off = unit_off[(ft0 + tile) * 192 + lane * 3 + chan];
-        const uint64_t pos = (start & 31) + off;
+    // tile-local exclusive offsets in scan order 3*block + chan
+    uint32_t dcl = 0;
+    {
+        auto count = [&](uint32_t, uint32_t len) { dcl += len; };
+        put_dc(dc - pred, s_dc[chan ? 1 : 0], count);
+    }
+    s_bits[lane * 3 + chan] = active ? dcl + aclen : 0u;
+    __syncthreads();
+    if (tid < 64) {
+        uint32_t a0 = s_bits[tid * 3], a1 = s_bits[tid * 3 + 1], a2 = s_bits[tid * 3 + 2];
+        uint32_t incl = wave_incl_scan(a0 + a1 + a2, tid);
+        uint32_t excl = incl - (a0 + a1 + a2);
+        s_bits[tid * 3] = excl;
+        s_bits[tid * 3 + 1] = excl + a0;
+        s_bits[tid * 3 + 2] = excl + a0 + a1;
+    }
+    __syncthreads();
+    if (active) {
+        const uint64_t pos = (start & 31) + s_bits[lane * 3 + chan];
+        auto body = [&](auto& bw) {
+            auto put = [&](uint32_t code, uint32_t len) { bw.put(code, len); };
+            put_dc(dc - pred, s_dc[chan ? 1 : 0], put);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if ((uint32_t)i * 32u < aclen) {
+                    uint32_t len = aclen - i * 32u < 32u ? aclen - i * 32u : 32u;
+                    bw.put(pre[i] >> (32u - len), len);
+                }
+            }
+            for (uint32_t done = 128; done < aclen; done += 32) {
+                uint32_t w = arena[m.x + (done >> 5)];
+                uint32_t len = aclen - done < 32u ? aclen - done : 32u;
+                bw.put(w >> (32u - len), len);
+            }
+            bw.flush();
+        };
         if (use_lds) {
             BitWriterLds bw{s_words, 0, (uint32_t)(pos & 31), (uint32_t)(pos >> 5)};
-            merge_unit(bw, dc - pred, s_dc[chan ? 1 : 0], arena, m.x, m.y >> 16);
+            body(bw);
         } else {
             BitWriterGlobal bw{outw, 0, (uint32_t)(pos & 31), w0 + (pos >> 5)};
-            merge_unit(bw, dc - pred, s_dc[chan ? 1 : 0], arena, m.x, m.y >> 16);
+            body(bw);
         }
     }
     if (!use_lds) return;
@@ -939,11 +1006,11 @@ hipError_t launch_meta_sizes(const Geom& g, uint32_t n_frames, const uint2* meta
     return hipGetLastError();
 }
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,
-                        const uint32_t* lut, const uint32_t* unit_off, const uint64_t* tile_off,
+                        const uint32_t* lut, const uint64_t* tile_off,
                         uint8_t* out, uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,
                         hipStream_t s) {
     if (lds_words_limit > kEmitLdsWords) lds_words_limit = kEmitLdsWords;
-    hipLaunchKernelGGL(k_merge, dim3(g.tiles, n_frames), dim3(192), 0, s, g, meta, arena, lut, unit_off,
+    hipLaunchKernelGGL(k_merge, dim3(g.tiles, n_frames), dim3(192), 0, s, g, meta, arena, lut,
                        tile_off, out, out_stride, status, lds_words_limit);
     return hipGetLastError();
 }

@@ -162,12 +162,13 @@ inline int hip_err(hipError_t e) { return e == hipSuccess ? MI355_OK : MI355_E_H
     } while (0)
 
 template <typename T>
-int ensure(T*& p, size_t& cap, size_t need) {
+int ensure(T*& p, size_t& cap, size_t need, bool zero = false) {
     if (need <= cap && p) return MI355_OK;
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
     if (hipMalloc((void**)&p, need * sizeof(T)) != hipSuccess) return MI355_E_ALLOC;
+    if (zero && hipMemset(p, 0, need * sizeof(T)) != hipSuccess) return MI355_E_ALLOC;
     cap = need;
     return MI355_OK;
 }
@@ -266,7 +267,7 @@ int ensure_workspace(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames) {
     int e;
     if ((e = ensure(c->d_coefs, c->coefs_cap, coef_dwords(g) * n_frames))) return e;
     if ((e = ensure(c->d_unit_off, c->unit_off_cap, unit_off_words(g) * n_frames))) return e;
-    if ((e = ensure(c->d_tile_bits, c->tiles_cap, (size_t)g.tiles * n_frames))) return e;
+    if ((e = ensure(c->d_tile_bits, c->tiles_cap, (size_t)g.tiles * n_frames, true))) return e;
     if ((e = ensure(c->d_tile_off, c->tile_off_cap, ((size_t)g.tiles + 1) * n_frames))) return e;
     return MI355_OK;
 }
@@ -316,6 +317,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.fixlist = c->d_fixlist;
     sp.fixcap = (uint32_t)((size_t)g.tiles * 3 * 64 * n_frames);
     sp.status = c->d_status;
+    sp.tile_bits = c->d_tile_bits;
     sp.coefs = coefs;
     sp.samples = nullptr;
     return sp;
@@ -366,8 +368,9 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
     HIP_TRY(launch_unit_sizes(g, n_frames, c->d_coefs, c->d_lut, c->d_unit_off, c->d_tile_bits,
                               c->d_status, s));
     record(c, 2, s);
+    // invariant: d_tile_bits is all zero between API calls (the screened pipeline accumulates into it)
     HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
-                             c->d_status, nullptr, s));
+                             c->d_status, nullptr, true, s));
     record(c, 3, s);
     HIP_TRY(launch_emit(g, n_frames, c->d_coefs, c->d_lut, c->d_unit_off, c->d_tile_off, d_out,
                         out_stride, c->d_status, c->emit_lds_words, s));
@@ -375,8 +378,8 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
     return MI355_OK;
 }
 
-// Screened pipeline: k_screen_encode -> k_fixup -> k_meta_sizes -> k_tile_scan -> k_merge.
-// The event slots keep their meaning: [0,1] transform (+ fix-up), [1,2] sizes, [2,3] scan, [3,4] emit.
+// Screened pipeline: k_screen_encode -> k_fixup -> k_tile_scan -> k_merge.
+// Event slots: [0,1] fused block encode (transform_ms), [1,2] exact fix-up (size_ms), [2,3] scan, [3,4] merge (emit_ms).
 int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t* d_rgb, uint8_t* d_out,
                  size_t out_stride, uint64_t* d_bits, hipStream_t s) {
     // AC blobs are word aligned per unit: at most total_bits/32 + one word per unit
@@ -389,14 +392,13 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     ScreenParams sp = screen_params(c, g, n_frames, plan, nullptr);
     record(c, 0, s);
     HIP_TRY(launch_screen_encode(g, n_frames, d_rgb, sp, false, c->screen_waves, s));
-    HIP_TRY(launch_fixup(g, d_rgb, sp, false, 256, s));
     record(c, 1, s);
-    HIP_TRY(launch_meta_sizes(g, n_frames, c->d_meta, c->d_lut, c->d_unit_off, c->d_tile_bits, c->d_status, s));
-    record(c, 2, s);
+    HIP_TRY(launch_fixup(g, d_rgb, sp, false, 32, s));
+    record(c, 2, s);  // slot [1,2] = exact fix-up (tile sums are accumulated by the encode kernel itself)
     HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
-                             c->d_status, c->d_counters, s));
+                             c->d_status, c->d_counters, true, s));
     record(c, 3, s);
-    HIP_TRY(launch_merge(g, n_frames, c->d_meta, c->d_arena, c->d_lut, c->d_unit_off, c->d_tile_off, d_out,
+    HIP_TRY(launch_merge(g, n_frames, c->d_meta, c->d_arena, c->d_lut, c->d_tile_off, d_out,
                          out_stride, c->d_status, c->emit_lds_words, s));
     record(c, 4, s);
     return MI355_OK;
@@ -411,8 +413,12 @@ int run_screened_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, u
     ScreenParams sp = screen_params(c, g, 1, plan, c->d_coefs);
     sp.samples = d_samples;
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(c->d_tile_bits, 0, (size_t)g.tiles * sizeof(uint32_t), s));
     HIP_TRY(launch_screen_encode(g, 1, d_rgb, sp, true, c->screen_waves, s));
-    HIP_TRY(launch_fixup(g, d_rgb, sp, true, 256, s));
+    HIP_TRY(launch_fixup(g, d_rgb, sp, true, 32, s));
+    // leave the accumulators re-armed for the next encode call
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(c->d_tile_bits, 0, (size_t)g.tiles * sizeof(uint32_t), s));
     return MI355_OK;
 }
 
@@ -582,7 +588,7 @@ int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t
     if (c->transform_mode == 2) {
         // only unit_off / tile arrays of the classic workspace are needed
         if ((e = ensure(c->d_unit_off, c->unit_off_cap, unit_off_words(g) * n_frames))) return e;
-        if ((e = ensure(c->d_tile_bits, c->tiles_cap, (size_t)g.tiles * n_frames))) return e;
+        if ((e = ensure(c->d_tile_bits, c->tiles_cap, (size_t)g.tiles * n_frames, true))) return e;
         if ((e = ensure(c->d_tile_off, c->tile_off_cap, ((size_t)g.tiles + 1) * n_frames))) return e;
         return run_screened(c, g, n_frames, (const uint8_t*)d_rgb, (uint8_t*)d_out, out_stride, d_bits, s);
     }
@@ -691,6 +697,7 @@ int mi355_jpeg_probe_unit_bits(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W
     if ((e = ensure(c->d_out, c->out_cap, ob))) return e;
     HIP_TRY(launch_unit_sizes(g, 1, c->d_coefs, c->d_lut, c->d_unit_off, c->d_tile_bits, c->d_status, nullptr));
     HIP_TRY(launch_unit_bits(g, c->d_unit_off, c->d_tile_bits, (uint32_t*)c->d_out, nullptr));
+    HIP_TRY(hipMemsetAsync(c->d_tile_bits, 0, (size_t)g.tiles * sizeof(uint32_t), nullptr));
     if ((e = mi355_jpeg_sync(c, nullptr))) return e;
     HIP_TRY(hipMemcpy(out, c->d_out, ob, hipMemcpyDeviceToHost));
     return MI355_OK;
