@@ -89,6 +89,9 @@ int mi355_jpeg_set_quality(mi355_jpeg_ctx *ctx, int quality);
 /* table: 0 DC luma, 1 DC chroma, 2 AC luma, 3 AC chroma (DC_LUMA_HUFF_CODES ...
  * AC_CHROMA_HUFF_CODES).  NULL restores the reference table. */
 int mi355_jpeg_set_huffman(mi355_jpeg_ctx *ctx, int table, const mi355_huff_table *t);
+/* The reference's own code table `table` (huffman.hpp, including the seven 17-bit
+ * AC-luma entries); host only, needs no device. */
+int mi355_jpeg_reference_huffman(int table, mi355_huff_table *t);
 int mi355_jpeg_get_quant(mi355_jpeg_ctx *ctx, uint32_t qlum[64], uint32_t qchrom[64]);
 int mi355_jpeg_get_huffman(mi355_jpeg_ctx *ctx, int table, mi355_huff_table *t);
 

@@ -43,7 +43,7 @@ class JpegError(RuntimeError):
 ABI_SYMBOLS = [
     "mi355_jpeg_abi_version", "mi355_jpeg_strerror", "mi355_jpeg_device_count", "mi355_jpeg_create",
     "mi355_jpeg_destroy", "mi355_jpeg_set_quant", "mi355_jpeg_set_quality", "mi355_jpeg_set_huffman",
-    "mi355_jpeg_get_quant", "mi355_jpeg_get_huffman", "mi355_jpeg_padded_size", "mi355_jpeg_scan_bound",
+    "mi355_jpeg_get_quant", "mi355_jpeg_get_huffman", "mi355_jpeg_reference_huffman", "mi355_jpeg_padded_size", "mi355_jpeg_scan_bound",
     "mi355_jpeg_encode_scan", "mi355_jpeg_encode_scan_device", "mi355_jpeg_sync", "mi355_jpeg_encode_jfif",
     "mi355_jpeg_probe_samples", "mi355_jpeg_probe_coefficients", "mi355_jpeg_probe_unit_bits",
     "mi355_jpeg_entropy_only", "mi355_jpeg_set_profiling", "mi355_jpeg_last_timings",
@@ -86,6 +86,7 @@ def lib():
         L.mi355_jpeg_set_huffman.argtypes = [vp, C.c_int, C.POINTER(HuffTable)]
         L.mi355_jpeg_get_quant.argtypes = [vp, vp, vp]
         L.mi355_jpeg_get_huffman.argtypes = [vp, C.c_int, C.POINTER(HuffTable)]
+        L.mi355_jpeg_reference_huffman.argtypes = [C.c_int, C.POINTER(HuffTable)]
         L.mi355_jpeg_padded_size.argtypes = [u32, u32, C.POINTER(u32), C.POINTER(u32)]
         L.mi355_jpeg_padded_size.restype = None
         L.mi355_jpeg_scan_bound.argtypes = [u32, u32]
@@ -114,6 +115,13 @@ def _check(status):
 
 def device_count():
     return lib().mi355_jpeg_device_count()
+
+
+def reference_huffman(table):
+    """(code, len) arrays of the reference's table (host only)."""
+    t = HuffTable()
+    _check(lib().mi355_jpeg_reference_huffman(table, C.byref(t)))
+    return np.array(t.code, np.uint32), np.array(t.len, np.uint8)
 
 
 def scan_bound(W, H):

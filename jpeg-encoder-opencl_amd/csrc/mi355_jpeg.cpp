@@ -549,6 +549,12 @@ int mi355_jpeg_set_huffman(mi355_jpeg_ctx* c, int table, const mi355_huff_table*
     return upload_tables(c);
 }
 
+int mi355_jpeg_reference_huffman(int table, mi355_huff_table* t) {
+    if (!t || table < 0 || table > 3) return MI355_E_ARG;
+    reference_huffman(table, t);
+    return MI355_OK;
+}
+
 int mi355_jpeg_get_quant(mi355_jpeg_ctx* c, uint32_t qlum[64], uint32_t qchrom[64]) {
     if (!c || !qlum || !qchrom) return MI355_E_ARG;
     memcpy(qlum, c->qlum, sizeof c->qlum);

@@ -1,0 +1,79 @@
+// Host-side C++ face of the MI355X encode path, shaped like the reference's interface
+// (src/utils.hpp + src/huffman.hpp) so that a JpegEncoderHost-style driver
+// (src/OpenCLProject_JpegEncoder.cpp:28-250) can be written against it.
+//
+// What is mirrored, and why only this much: the reference's interface is a bag of
+// in-place stage functions over host images (performCSC(ppm_t*), performCDS(ppm_t*), ...
+// utils.hpp:77-137).  The GPU path is fused -- those intermediates never exist in memory
+// -- so the shim exposes the reference's data types, its constant tables, its PPM I/O
+// helpers, and the path at the three granularities the library has:
+//     JpegEncoderDevice()        = the whole of JpegEncoderHost's stage sequence (:59-225)
+//     transformToZigZag()        = performCSC ... performZigZag            (:59-197)
+//     HuffmanEncoder(zigzag, n)  = performRLE + HuffmanEncoder             (:213-225)
+// All compute happens in libmi355jpeg.so (include/mi355_jpeg.h); nothing here falls back
+// to the CPU.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355_jpeg.h"
+
+// ---- data types (utils.hpp:7-39) -------------------------------------------------
+struct rgb_pixel {
+    uint8_t r, g, b;
+};
+typedef struct rgb_pixel rgb_pixel_t;
+struct PPMimage {
+    size_t width, height;
+    rgb_pixel_t* data;
+};
+typedef struct PPMimage ppm_t;
+
+// ---- constant tables (utils.hpp:41-62, huffman.hpp) -------------------------------
+// Same names, types and indexing as the reference: [v][u] for the quantisation tables,
+// [size] / [run][size] '0'/'1' strings for the code tables ("NULL" where the reference
+// has no code; AC_LUMA_HUFF_CODES[3][4..10] are the 17-character entries).
+extern const unsigned int quant_mat_lum[8][8];
+extern const unsigned int quant_mat_chrom[8][8];
+extern const std::vector<std::string> DC_LUMA_HUFF_CODES;
+extern const std::vector<std::string> DC_CHROMA_HUFF_CODES;
+extern const std::vector<std::vector<std::string>> AC_LUMA_HUFF_CODES;
+extern const std::vector<std::vector<std::string>> AC_CHROMA_HUFF_CODES;
+
+// ---- telemetry (role of CPUTelemetry, utils.hpp:65-75), microseconds ---------------
+struct GPUTelemetry {
+    double blockEncodeTime;  // fused CSC .. per-unit RLE/Huffman strings (k_screen_encode)
+    double fixupTime;        // exact fp64 chain for undecided units (k_fixup)
+    double scanTime;         // prefix sum of tile bit counts
+    double emitTime;         // final bit string
+    double totalTime;        // device time of the whole path
+    double wallTime;         // host wall clock incl. PCIe transfers
+};
+
+// ---- PPM I/O (utils.cpp:11-82): same contract: 0 ok, -1 + message on stdout ------------
+int readPPMImage(const char* path, size_t* width, size_t* height, rgb_pixel_t** img);
+int writePPMImage(const char* path, size_t width, size_t height, rgb_pixel_t* img);
+void getNearest8x8ImageSize(size_t width, size_t height, size_t* newWidth, size_t* newHeight);
+
+// ---- the encode path -----------------------------------------------------------------
+// One process-wide context on `device` (created on first use); quality 50 = the
+// reference's tables.  All return 0 on success, 1 on error (message on stdout), like
+// JpegEncoderHost.
+int mi355_select(int device, int quality);
+
+// The whole stage sequence of JpegEncoderHost; *scanData receives the '0'/'1' string
+// that the reference's HuffmanEncoder returns (utils.cpp:697).
+int JpegEncoderDevice(ppm_t img, GPUTelemetry* telemetry = NULL, std::string* scanData = NULL,
+                      bool chroma_downsample = true);
+
+// performCSC .. performZigZag: zigzag_arr must hold 3*N rows (N = padded blocks), row
+// order chan*N + block as everyMCUisnow2DArray lays it out (utils.cpp:482-498).
+int transformToZigZag(ppm_t img, int zigzag_arr[][64], bool chroma_downsample = true);
+
+// performRLE + HuffmanEncoder on a coefficient array in that row order.
+std::string HuffmanEncoder(int zigzag_arr[][64], int numRowsPerChannel);
+
+// Build-defined JFIF file around the scan (the reference writes none).
+int writeJpegFile(const char* path, ppm_t img, bool chroma_downsample = true);

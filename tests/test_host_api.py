@@ -1,0 +1,73 @@
+"""The utils.hpp-shaped C++ host API and the command line tool: built with
+g++ against libmi355jpeg.so; on the GPU box driven like the reference's JpegEncoderHost
+and compared with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import GOLD, ROOT
+
+PKG = os.path.join(ROOT, "jpeg-encoder-opencl_amd")
+CLI = os.path.join(PKG, "host", "mi355-jpeg")
+
+
+def build_host(tmp_path):
+    subprocess.check_call(["make", "-s", "-C", PKG, "all", "host"])
+    exe = str(tmp_path / "host_driver")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "host_driver.cpp"),
+                           os.path.join(PKG, "host", "libmi355host.a"), "-L" + PKG, "-lmi355jpeg",
+                           "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_host_api_builds_and_tables_match(tmp_path, jpeg):
+    """No GPU needed: the shim compiles, the CLI parses arguments, and the four code
+    tables it publishes as huffman.hpp-style strings equal the reference dump."""
+    import json
+    exe = build_host(tmp_path)
+    assert subprocess.call([CLI, "--help"]) == 0
+    prefix = str(tmp_path / "o")
+    rc = subprocess.call([exe, os.path.join(GOLD, "fruit.ppm"), prefix])
+    if jpeg.device_count() == 0:
+        assert rc == 1  # fails loudly: no CPU path
+    lines = open(prefix + ".tables").read().split("\n")
+    with open(os.path.join(GOLD, "tables.json")) as f:
+        t = json.load(f)["huffman"]
+    want = [s or "NULL" for s in t["dc_luma"][0]] + [s or "NULL" for s in t["dc_chroma"][0]]
+    for name in ("ac_luma", "ac_chroma"):
+        for row in t[name]:
+            want += [s or "NULL" for s in row]
+    assert lines[:len(want)] == want
+    assert lines[len(want)] == "99 18"
+
+
+@pytest.mark.gpu
+def test_host_driver_matches_oracle(tmp_path):
+    exe = build_host(tmp_path)
+    for (q, cds) in [(50, True), (90, False)]:
+        prefix = str(tmp_path / ("o%d" % q))
+        subprocess.check_call([exe, os.path.join(GOLD, "fruit.ppm"), prefix, str(q), "1" if cds else "0"])
+        rgb = ol.read_ppm(os.path.join(GOLD, "fruit.ppm"))
+        ql, qc = ol.quant_tables(q)
+        o = ol.oracle_encode(rgb, ql, qc, cds)
+        want = "".join(str(b) for b in np.unpackbits(o.bits)[:o.n_bits])
+        assert open(prefix + ".bits").read() == want
+        assert open(prefix + ".bits2").read() == want
+        assert open(prefix + ".jpg", "rb").read() == ol.jfif_frame(o.bits, o.n_bits, rgb.shape[1], rgb.shape[0], ql, qc)
+
+
+@pytest.mark.gpu
+def test_cli_ppm_to_jpg(tmp_path):
+    subprocess.check_call(["make", "-s", "-C", PKG, "all", "host"])
+    out = str(tmp_path / "fruit.jpg")
+    bits = str(tmp_path / "fruit.bits")
+    subprocess.check_call([CLI, os.path.join(GOLD, "fruit.ppm"), out, "--bits", bits, "--repeat", "2"])
+    rgb = ol.read_ppm(os.path.join(GOLD, "fruit.ppm"))
+    ql, qc = ol.quant_tables(50)
+    o = ol.oracle_encode(rgb)
+    assert open(out, "rb").read() == ol.jfif_frame(o.bits, o.n_bits, rgb.shape[1], rgb.shape[0], ql, qc)
+    assert len(open(bits).read()) == 307829
+    assert subprocess.call([CLI, "/nonexistent.ppm", out]) == 1
