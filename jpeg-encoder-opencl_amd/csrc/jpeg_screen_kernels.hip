@@ -30,6 +30,7 @@
 namespace mi355 {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr uint32_t kSlotWordsFull = 54;  // worst case 63*(17+10)+4 = 1705 bits
 
@@ -453,7 +454,8 @@ __global__ void __launch_bounds__(256, 2)
     __shared__ uint32_t s_slot_all[kEncWaves][(kSlotRows + 1) * 64];  // AC strings [word][lane] + dump row
     __shared__ uint32_t s_mask_all[kEncWaves][2][64];              // non-zero masks (lo, hi)
     __shared__ uint32_t s_flag_all[kEncWaves][64];
-    __shared__ double s_qc[2][64][4];   // {s1, thr1, s2, thr2} per channel type and zig-zag position
+    __shared__ double s_qc[2][64][4];   // {s1, thr1, s2, thr2} per channel type and zig-zag position (fp64 looks)
+    __shared__ float s_qf[2][16][8];    // per group of 4 positions: 2^-20/Q x4, first-look thresholds x4
     __shared__ uint32_t s_act[2][256];  // (run,size) AC tables
     __shared__ uint32_t s_lut2[2][1024];  // (run,value) symbol tables
     __shared__ uint32_t s_dc[2][16];      // DC tables
@@ -469,6 +471,7 @@ __global__ void __launch_bounds__(256, 2)
         (&s_act[0][0])[i] = sp.lut[512 + i];
     }
     for (uint32_t i = tid; i < 2048; i += 256) (&s_lut2[0][0])[i] = sp.lut2[i];
+    (&s_qf[0][0][0])[tid] = sp.qconst_f[tid];
     if (tid < 32) s_dc[tid >> 4][tid & 15] = sp.lut[(tid >> 4) * 256 + (tid & 15)];
     // A fragments of digits 1..4 stay in registers; digit 0 only matters for the (rare)
     // second look and is fetched on demand.
@@ -600,29 +603,44 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
                 for (int l = 0; l < kScreenLimbs - 1; ++l)
                     acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mt][l], B, v4i{0, 0, 0, 0}, 0, 0, 0);
-                int q[4];
-                double y1s[4];
+                // ---- first look in packed fp32.  V = floor(Y1 / 2^11), Y1 = hi*2^16 + mid (digits
+                // 4..1, exact integers), so c/Q = V*2^-20/Q + e with |e| < (2^-18 + delta)/Q (dropped
+                // low bits and digit 0, map error).  zf = fl(fl(V) * fl(2^-20/Q)) is within |z|*2^-22 of
+                // V*2^-20/Q.  rn = nearest integer of zf by the 1.5*2^23 trick, d = zf - rn exact.
+                // The quantised value is rn whenever |d| + |zf|*2^-21 < 0.5 - (2^-18 + delta)/Q.
+                int hi[4], mid[4];
+                v2f fA, fB;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    hi[r] = acc[3][r] * 256 + acc[2][r];
+                    mid[r] = acc[1][r] * 256 + acc[0][r];
+                    const float fv = (float)((hi[r] << 5) + (mid[r] >> 11));
+                    if (r < 2) fA[r] = fv;
+                    else fB[r - 2] = fv;
+                }
+                const float* qf = &s_qf[ct][4 * mt + gq][0];  // sf[4], thr[4] of positions 16mt+4gq..+3
+                const v2f sA = {qf[0], qf[1]}, sB = {qf[2], qf[3]};
+                const v2f M2 = {12582912.0f, 12582912.0f};
+                const v2f zA = fA * sA, zB = fB * sB;
+                const v2f aA = zA + M2, aB = zB + M2;
+                const v2f rA = aA - M2, rB = aB - M2;
+                const v2f dA = zA - rA, dB = zB - rB;
+                const float zz[4] = {zA[0], zA[1], zB[0], zB[1]};
+                const float aa[4] = {aA[0], aA[1], aB[0], aB[1]};
+                const float dd[4] = {dA[0], dA[1], dB[0], dB[1]};
+                uint32_t qb[4];  // low 16 bits = quantised value
                 bool a1[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int hi = acc[3][r] * 256 + acc[2][r];
-                    const int mid = acc[1][r] * 256 + acc[0][r];
-                    const double y1 = (double)hi * 65536.0 + (double)mid;  // exact
-                    const double* qc = &s_qc[ct][16 * mt + 4 * gq + r][0];
-                    const double z = y1 * qc[0];
-                    const double t = __builtin_fabs(z) + 0.5;
-                    const double fr = t - __builtin_floor(t);
-                    const int nn = (int)t;
-                    a1[r] = !(__builtin_fabs(fr - 0.5) < qc[1]);
-                    q[r] = z < 0.0 ? -nn : nn;
-                    y1s[r] = y1;
+                    qb[r] = __float_as_uint(aa[r]);  // 0x4B400000 + q
+                    a1[r] = !(__builtin_fmaf(__builtin_fabsf(zz[r]), 0x1p-21f, __builtin_fabsf(dd[r])) < qf[4 + r]);
                     if (mt == 0 && r == 0 && gq == 0) {
-                        q[r] = q0;  // coefficient 0 is formed exactly
+                        qb[r] = (uint32_t)q0;  // coefficient 0 is formed exactly
                         a1[r] = false;
                     }
                 }
                 if (__any(a1[0] || a1[1] || a1[2] || a1[3])) {
-                    // second look with the least significant digit included (wave-uniform, rare)
+                    // second look in fp64 with the least significant digit included (wave-uniform, rare)
                     uint4 t0 = sp.afrag[(mt * kScreenLimbs) * 64 + lane];
                     v4i acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w}, B,
                                                                      v4i{0, 0, 0, 0}, 0, 0, 0);
@@ -630,22 +648,23 @@ __global__ void __launch_bounds__(256, 2)
                     for (int r = 0; r < 4; ++r) {
                         if (a1[r]) {
                             const double* qc = &s_qc[ct][16 * mt + 4 * gq + r][0];
-                            const double y2 = y1s[r] * 256.0 + (double)acc0[r];  // exact
+                            const double y1 = (double)hi[r] * 65536.0 + (double)mid[r];  // exact
+                            const double y2 = y1 * 256.0 + (double)acc0[r];              // exact
                             const double z = y2 * qc[2];
                             const double t = __builtin_fabs(z) + 0.5;
                             const double fr = t - __builtin_floor(t);
                             const int nn = (int)t;
-                            q[r] = z < 0.0 ? -nn : nn;
+                            qb[r] = (uint32_t)(z < 0.0 ? -nn : nn);
                             amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
                         }
                     }
                 }
                 // zig-zag positions 16mt+4gq .. +3 of unit 16j+n -> transpose buffer + non-zero bits
                 uint32_t* row = &s_tbuf[(16 * j + n) * 33 + 8 * mt + 2 * gq];
-                row[0] = ((uint32_t)q[0] & 0xffffu) | ((uint32_t)q[1] << 16);
-                row[1] = ((uint32_t)q[2] & 0xffffu) | ((uint32_t)q[3] << 16);
-                const uint32_t nib = (q[0] != 0 ? 1u : 0u) | (q[1] != 0 ? 2u : 0u) | (q[2] != 0 ? 4u : 0u) |
-                                     (q[3] != 0 ? 8u : 0u);
+                row[0] = (qb[0] & 0xffffu) | (qb[1] << 16);
+                row[1] = (qb[2] & 0xffffu) | (qb[3] << 16);
+                const uint32_t nib = ((qb[0] & 0xffffu) ? 1u : 0u) | ((qb[1] & 0xffffu) ? 2u : 0u) |
+                                     ((qb[2] & 0xffffu) ? 4u : 0u) | ((qb[3] & 0xffffu) ? 8u : 0u);
                 if (mt < 2) nzlo |= nib << (16 * mt);
                 else nzhi |= nib << (16 * (mt - 2));
             }

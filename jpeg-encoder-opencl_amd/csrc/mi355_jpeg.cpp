@@ -134,6 +134,7 @@ struct mi355_jpeg_ctx {
     // screened (integer-MFMA) pipeline
     uint4* d_afrag = nullptr;       // MFMA A fragments of the fixed-point map (static)
     double* d_qconst = nullptr;     // [2][64][4] accept thresholds for the current tables
+    float* d_qconst_f = nullptr;    // [2][16][8] fp32 first-look scale factors and thresholds
     uint32_t* d_lut2 = nullptr;     // [2][16][64] whole AC symbols for |value| <= 31
     uint32_t* d_counters = nullptr; // [0] arena words, [1] fix-up list length
     uint2* d_meta = nullptr;
@@ -205,6 +206,25 @@ int upload_tables(mi355_jpeg_ctx* c) {
             qc[ct][R][3] = tau2 < 0.5 ? 0.5 - tau2 : -1.0;
         }
     HIP_TRY(hipMemcpy(c->d_qconst, qc, sizeof qc, hipMemcpyHostToDevice));
+    // First look in fp32 (k_screen_encode): zf = fl(fl(V) * sf), V = floor(Y1/2^11), sf = fl(2^-20/Q).
+    // |c/Q - V*2^-20/Q| < (2^-18 + delta)/Q (dropped low bits of Y1, digit 0, map error) and
+    // |zf - V*2^-20/Q| <= |z|*2^-22 (three fp32 roundings), the latter covered in the kernel by the
+    // |zf|*2^-21 term; thr = 0.5 - tau - 2^-22 (float rounding of thr itself and of the test).
+    float qf[2][16][8];
+    for (int ct = 0; ct < 2; ++ct)
+        for (int grp = 0; grp < 16; ++grp)
+            for (int r = 0; r < 4; ++r) {
+                const int R = 16 * (grp >> 2) + 4 * (grp & 3) + r;
+                const double Q = (double)(ct ? c->qchrom[zz[R]] : c->qlum[zz[R]]);
+                const double delta = kScreenEps[R] + kScreenFixErr;
+                const double tau = ((std::ldexp(1.0, -18) + delta) / Q * 1.000001) * c->tau_scale + std::ldexp(1.0, -22);
+                qf[ct][grp][r] = (float)(std::ldexp(1.0, -20) / Q);
+                // round the threshold DOWN to float
+                float th = tau < 0.5 ? (float)(0.5 - tau) : -1.0f;
+                if (tau < 0.5 && (double)th > 0.5 - tau) th = std::nextafterf(th, -1.0f);
+                qf[ct][grp][4 + r] = th;
+            }
+    HIP_TRY(hipMemcpy(c->d_qconst_f, qf, sizeof qf, hipMemcpyHostToDevice));
     // Whole-symbol tables of the screened pipeline's unit walk: for run r and value v (|v| <= 31)
     // the Huffman code of (r, size(v)) followed by v's value bits, left-aligned in 32 bits, with
     // the total length in bits 4..0; 0 = the reference has no code.  (15, 0) = ZRL; the spare
@@ -307,6 +327,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.overflow_base = plan.grid * plan.region_words;
     sp.afrag = c->d_afrag;
     sp.qconst = c->d_qconst;
+    sp.qconst_f = c->d_qconst_f;
     sp.qd = c->d_q;
     sp.lut = c->d_lut;
     sp.lut2 = c->d_lut2;
@@ -480,6 +501,7 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
         hipMalloc((void**)&c->d_status, sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_afrag, (size_t)4 * kScreenLimbs * 64 * 16) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&c->d_qconst_f, 256 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut2, 2048 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_counters, 2 * sizeof(uint32_t)) != hipSuccess)
         e = MI355_E_ALLOC;
@@ -500,7 +522,7 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
                     c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
-                    c->d_counters, c->d_meta,     c->d_arena,  c->d_fixlist, c->d_lut2};
+                    c->d_counters, c->d_meta,     c->d_arena,  c->d_fixlist, c->d_lut2,     c->d_qconst_f};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& es : c->ev_pool)
