@@ -41,6 +41,7 @@ struct ScreenParams {
     uint32_t* tile_bits;    // [frame][tile] bit totals, accumulated with atomics (zero on entry)
     uint32_t* coefs;        // probe output (tiled coefficient layout) or nullptr
     uint8_t* samples;       // probe output (padded YCbCr image, interleaved) or nullptr
+    unsigned long long* stamps;  // diagnostic build only (-DMI355_STAMPS): [wave][8] phase cycle sums
 };
 
 // number of persistent single-wave workgroups launch_screen_encode will use

@@ -447,6 +447,22 @@ __device__ __forceinline__ bool walk_nonzeros(const int16_t* row, uint64_t mask,
 // ----------------------------------------------------------------------------
 constexpr uint32_t kEncWaves = 4;
 
+// Diagnostic build (make STAMPS=1): s_memtime stamps at the phase boundaries of a wave
+// iteration, summed per wave and written to sp.stamps.  Never in the shipped kernel.
+#ifdef MI355_STAMPS
+#define STAMP(i)                                                                         \
+    do {                                                                                 \
+        unsigned long long _t;                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        stamp_sum[i] += _t - stamp_prev;                                                 \
+        stamp_prev = _t;                                                                 \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 template <bool PROBE>
 __global__ void __launch_bounds__(256, 2)
     k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
@@ -501,7 +517,12 @@ __global__ void __launch_bounds__(256, 2)
     const uint32_t pstep = xcd_map ? local_n : gridDim.x * kEncWaves;
 
     WaveArena wa{gwave * sp.region_words, sp.region_words};
+#ifdef MI355_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     for (uint32_t p = pstart; p < pairs_total; p += pstep) {
+        STAMP(7);
         uint32_t frame, tile, chan;
         if (xcd_map) {
             const uint32_t pf = tiles_x * 3u;
@@ -545,6 +566,25 @@ __global__ void __launch_bounds__(256, 2)
             }
         }
         const bool fast = g.fast_rows && __all(interior);
+
+        // The DC difference of lane 0 needs the last block of the previous tile: its DC is
+        // recomputed from its 64 samples, one pixel per lane.  When that block lies inside the
+        // image its three bytes per lane are fetched NOW and consumed after the walk.
+        uint32_t pbx = 0, pby = 0, pr = 0, pg = 0, pbl = 0;
+        bool pred_fast = false;
+        if (tile > 0) {
+            const uint32_t pb = tile * 64 - 1;
+            pby = pb / g.nbx;
+            pbx = pb - pby * g.nbx;
+            pred_fast = (pbx * 8 + 8 <= g.W) && (pby * 8 + 8 <= g.H);
+            if (pred_fast) {
+                const uint8_t* pp = f + ((size_t)(pby * 8 + (lane >> 3)) * g.W + pbx * 8 + (lane & 7)) * 3;
+                pr = pp[0];
+                pg = pp[1];
+                pbl = pp[2];
+            }
+        }
+        STAMP(0);
 
         s_flag[lane] = 0;
         s_mlo[lane] = 0;
@@ -673,6 +713,7 @@ __global__ void __launch_bounds__(256, 2)
             if (amb) s_flag[16 * j + n] = 1;
         }
         __builtin_amdgcn_wave_barrier();
+        STAMP(1);
 
         // ---- walk phase: lane = block
         const uint32_t b = tile * 64 + lane;
@@ -692,6 +733,7 @@ __global__ void __launch_bounds__(256, 2)
         bool ok = walk_nonzeros(row16, mask, s_lut2[ct], s_act[ct], pkr);
         const uint32_t aclen = pkr.bits();
         uint32_t nw = pkr.words();
+        STAMP(2);
         const bool oversize = nw > kSlotRows;
         if (!active) flagged = false;
         if (!ok && active && !flagged) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY (decided coefficients only)
@@ -705,9 +747,17 @@ __global__ void __launch_bounds__(256, 2)
         {
             int pred0 = 0;
             if (tile > 0) {
-                const uint32_t pb = tile * 64 - 1;
-                const uint32_t pby = pb / g.nbx, pbx = pb - pby * g.nbx;
-                uint32_t sm = sample_generic_int(f, g, (int)chan, avg, pbx * 8 + (lane & 7), pby * 8 + (lane >> 3));
+                uint32_t sm;
+                if (pred_fast) {
+                    sm = chan == 0 ? csc_int(0, pr, pg, pbl) : (chan == 1 ? csc_int(1, pr, pg, pbl) : csc_int(2, pr, pg, pbl));
+                    if (avg) {  // 2x2 mean of the quad (lane = y*8+x: partners x^1, y^1)
+                        uint32_t s4 = sm + (uint32_t)__shfl_xor((int)sm, 1);
+                        s4 += (uint32_t)__shfl_xor((int)s4, 8);
+                        sm = s4 >> 2;
+                    }
+                } else {
+                    sm = sample_generic_int(f, g, (int)chan, avg, pbx * 8 + (lane & 7), pby * 8 + (lane >> 3));
+                }
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) sm += (uint32_t)__shfl_xor((int)sm, d);
                 const double pc0 = (double)((int)sm - 8192) * kScale00;
@@ -725,6 +775,7 @@ __global__ void __launch_bounds__(256, 2)
             if (lane == 0 && ubits) atomicAdd(&sp.tile_bits[(size_t)frame * g.tiles + tile], ubits);
         }
 
+        STAMP(3);
         // arena space: regular strings back to back; oversized ones get a full-size private run
         const uint32_t need = oversize && nw ? kSlotWordsFull : nw;
         const uint32_t incl = wave_incl_scan(need, lane);
@@ -734,8 +785,12 @@ __global__ void __launch_bounds__(256, 2)
         if (!fits) {
             if (lane == 0) atomicOr(sp.status, 2u);  // MI355_E_CAPACITY
         } else {
-            for (uint32_t w = 0; __any(w < nw && !oversize); ++w)
-                if (w < nw && !oversize) sp.arena[off + w] = s_slot[w * 64 + lane];
+            const uint32_t ncopy = oversize ? 0u : nw;
+#pragma unroll
+            for (uint32_t w = 0; w < 8; ++w)
+                if (w < ncopy) sp.arena[off + w] = s_slot[w * 64 + lane];
+            for (uint32_t w = 8; __any(w < ncopy); ++w)
+                if (w < ncopy) sp.arena[off + w] = s_slot[w * 64 + lane];
             if (__any(oversize && nw)) {  // rare: string longer than the LDS slot: walk again, straight to memory
                 if (oversize && nw) {
                     Packer32<StoreGlobal> pg(StoreGlobal{sp.arena + off});
@@ -749,7 +804,12 @@ __global__ void __launch_bounds__(256, 2)
             if (k < sp.fixcap) sp.fixlist[k] = (uint32_t)(us_base + lane);
         }
         __builtin_amdgcn_wave_barrier();
+        STAMP(4);
     }
+#ifdef MI355_STAMPS
+    if (sp.stamps && lane == 0)
+        for (int i = 0; i < 8; ++i) sp.stamps[(size_t)gwave * 8 + i] = stamp_sum[i];
+#endif
 }
 
 // ----------------------------------------------------------------------------

@@ -147,6 +147,7 @@ struct mi355_jpeg_ctx {
     uint32_t screen_waves = 2048;   // persistent single-wave workgroups of k_screen_encode
     int transform_mode = 2;         // 0 exact fp64 chain (unrolled), 1 exact (looped), 2 screened MFMA + exact fix-up
     uint32_t emit_lds_words = 4096;
+    unsigned long long* d_stamps = nullptr;  // diagnostic build only
     int profiling = 0;              // 0 off, 1 all stages, 2 transform only
     std::vector<EventSet> ev_pool;  // grown on demand, reused after a reset
     size_t ev_used = 0;             // sets recorded since profiling was enabled
@@ -341,6 +342,15 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.tile_bits = c->d_tile_bits;
     sp.coefs = coefs;
     sp.samples = nullptr;
+    sp.stamps = nullptr;
+#ifdef MI355_STAMPS
+    {   // diagnostic build: one lazily allocated buffer, dumped by mi355_jpeg_sync
+        static unsigned long long* d_st = nullptr;
+        if (!d_st) (void)hipMalloc((void**)&d_st, 8192 * 8 * sizeof(unsigned long long));
+        sp.stamps = d_st;
+        c->d_stamps = d_st;
+    }
+#endif
     return sp;
 }
 
@@ -631,6 +641,17 @@ int mi355_jpeg_sync(mi355_jpeg_ctx* c, void* stream) {
     if (!c) return MI355_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+#ifdef MI355_STAMPS
+    if (c->d_stamps && getenv("MI355_JPEG_DUMP_STAMPS")) {
+        std::vector<unsigned long long> h(2048 * 8);
+        (void)hipMemcpy(h.data(), c->d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        double sum[8] = {0};
+        for (int w = 0; w < 2048; ++w)
+            for (int i = 0; i < 8; ++i) sum[i] += (double)h[(size_t)w * 8 + i];
+        fprintf(stderr, "[stamps] cycles per wave: setup %.0f | samples+mfma+post %.0f | walk %.0f | dc/sizes %.0f | arena+meta %.0f | loop %.0f\n",
+                sum[0] / 2048, sum[1] / 2048, sum[2] / 2048, sum[3] / 2048, sum[4] / 2048, sum[7] / 2048);
+    }
+#endif
     uint32_t st = 0;
     HIP_TRY(hipMemcpy(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
     if (st) HIP_TRY(hipMemset(c->d_status, 0, sizeof st));
