@@ -385,3 +385,43 @@ def test_large_single_frame_8192(jpeg, enc):
     for c in range(3):
         assert np.array_equal(cf[c * N + first:c * N + first + Ns].astype(np.int32),
                               o.zigzag[c * Ns:(c + 1) * Ns])
+
+
+def test_config5_16384_square_q90_nocds(jpeg, enc):
+    """configs[4]: single 16384x16384 frame, q=90, no chroma averaging.  The reference build's
+    scan is 3 938 207 090 bits (> 2^32: 64-bit offsets in the prefix scan) with SHA-256
+    22a3a76e... (measured from the reference's own utils.cpp)."""
+    import ctypes as C
+    W = H = 16384
+    rgb = ol.lcg_frame(W, H, 1)
+    set_quality(enc, 90)
+    cap = 520 << 20
+    out = np.zeros(cap, np.uint8)
+    bits = (C.c_uint64 * 1)()
+    rc = jpeg.lib().mi355_jpeg_encode_scan(enc._h, rgb.ctypes.data, W, H, 1, 0, out.ctypes.data, cap, bits)
+    assert rc == 0, rc
+    nb = int(bits[0])
+    assert nb == 3938207090
+    h = hashlib.sha256()
+    chunk = 1 << 24  # bytes of packed bits per step
+    nbytes = (nb + 7) // 8
+    for o in range(0, nbytes, chunk):
+        part = np.unpackbits(out[o:min(o + chunk, nbytes)])
+        if o + chunk >= nbytes:
+            part = part[:nb - o * 8]
+        h.update((part + ord("0")).astype(np.uint8).tobytes())
+    assert h.hexdigest() == "22a3a76e3a7ceb82d483d31262f3b67bce5668bed019bcca7f457094bb64fe54"
+
+
+def test_config3_batch_of_1080p_frames_q75(jpeg, enc):
+    """configs[2] shape: a batch of 1920x1080 frames at q=75 in one call (48 of the 1024
+    frames; seed 1 is pinned by the reference build: 15 834 765 bits, SHA 8ddd2258...)."""
+    n, W, H = 48, 1920, 1080
+    frames = np.stack([ol.lcg_frame(W, H, 1 + f) for f in range(n)])
+    ql, qc = set_quality(enc, 75)
+    bits, nb = enc.encode_scan(frames, cap=3 << 20)
+    assert nb[0] == 15834765
+    assert ascii_sha(bits[0], nb[0]) == "8ddd22589f8131edcba723180fb581ef5efcf906f4de159b58de671ee34bb280"
+    for f in (1, 17, 47):
+        o = ol.oracle_encode(frames[f], ql, qc, True)
+        assert nb[f] == o.n_bits and np.array_equal(bits[f], o.bits)
