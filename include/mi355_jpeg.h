@@ -153,6 +153,26 @@ int mi355_jpeg_probe_unit_bits(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t
 int mi355_jpeg_entropy_only(mi355_jpeg_ctx *ctx, const int16_t *zigzag, uint32_t n_blocks,
                             uint8_t *out, size_t cap, uint64_t *bits);
 
+/* ---- multi-GPU batch driver (host frames in, host scans out) -------------
+ * The production shape of BASELINE configs[3]: a batch of independent frames sharded
+ * across the GPUs of one node, no collective.  One worker thread + one context per
+ * entry of device_ids (an id may repeat: several workers on one GPU); each worker takes
+ * a contiguous slab of frames and streams it through the device in chunks with
+ * H2D(k+1) || encode(k) || D2H(k-1) on separate HIP streams.  Same results as
+ * mi355_jpeg_encode_scan frame by frame. */
+typedef struct mi355_jpeg_pool mi355_jpeg_pool;
+/* device_ids NULL: every visible device once. */
+int mi355_jpeg_pool_create(const int *device_ids, int n_workers, mi355_jpeg_pool **pool);
+void mi355_jpeg_pool_destroy(mi355_jpeg_pool *pool);
+int mi355_jpeg_pool_workers(mi355_jpeg_pool *pool);
+int mi355_jpeg_pool_set_quant(mi355_jpeg_pool *pool, const uint32_t qlum[64], const uint32_t qchrom[64]);
+int mi355_jpeg_pool_set_quality(mi355_jpeg_pool *pool, int quality);
+/* out: frame f at out + f*out_stride; bits[f] its bit count.  seconds (may be NULL)
+ * receives the wall time of the call (PCIe-inclusive). */
+int mi355_jpeg_pool_encode(mi355_jpeg_pool *pool, const uint8_t *rgb, uint32_t W, uint32_t H,
+                           uint32_t n_frames, uint32_t flags, uint8_t *out, size_t out_stride,
+                           uint64_t *bits, double *seconds);
+
 /* ---- measurement ------------------------------------------------------- */
 /* mode 0: off (default).  mode 1: HIP events around every stage of each encode
  * call, recorded on the call's stream.  mode 2: events around the transform

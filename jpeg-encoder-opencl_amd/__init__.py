@@ -47,7 +47,8 @@ ABI_SYMBOLS = [
     "mi355_jpeg_encode_scan", "mi355_jpeg_encode_scan_device", "mi355_jpeg_sync", "mi355_jpeg_encode_jfif",
     "mi355_jpeg_probe_samples", "mi355_jpeg_probe_coefficients", "mi355_jpeg_probe_unit_bits",
     "mi355_jpeg_entropy_only", "mi355_jpeg_set_profiling", "mi355_jpeg_last_timings",
-    "mi355_jpeg_profile_summary",
+    "mi355_jpeg_profile_summary", "mi355_jpeg_pool_create", "mi355_jpeg_pool_destroy", "mi355_jpeg_pool_workers",
+    "mi355_jpeg_pool_set_quant", "mi355_jpeg_pool_set_quality", "mi355_jpeg_pool_encode",
 ]
 
 _lib = None
@@ -102,6 +103,13 @@ def lib():
         L.mi355_jpeg_set_profiling.argtypes = [vp, C.c_int]
         L.mi355_jpeg_last_timings.argtypes = [vp, C.POINTER(Timings)]
         L.mi355_jpeg_profile_summary.argtypes = [vp, C.POINTER(Timings), C.POINTER(u32)]
+        L.mi355_jpeg_pool_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+        L.mi355_jpeg_pool_destroy.argtypes = [vp]
+        L.mi355_jpeg_pool_destroy.restype = None
+        L.mi355_jpeg_pool_workers.argtypes = [vp]
+        L.mi355_jpeg_pool_set_quant.argtypes = [vp, vp, vp]
+        L.mi355_jpeg_pool_set_quality.argtypes = [vp, C.c_int]
+        L.mi355_jpeg_pool_encode.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, u64p, C.POINTER(C.c_double)]
         for name in ABI_SYMBOLS:  # fail at load time, not at first use, if a symbol is missing
             getattr(L, name)
         _lib = L
@@ -260,3 +268,52 @@ class Encoder:
         t = Timings()
         _check(lib().mi355_jpeg_last_timings(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in Timings._fields_}
+
+
+class Pool:
+    """Multi-GPU batch driver: host frames in, host scans out, frames sharded over the
+    workers (one context + thread per entry of device_ids), no collective."""
+
+    def __init__(self, device_ids=None):
+        self._h = C.c_void_p()
+        if device_ids is None:
+            _check(lib().mi355_jpeg_pool_create(None, 0, C.byref(self._h)))
+        else:
+            arr = (C.c_int * len(device_ids))(*device_ids)
+            _check(lib().mi355_jpeg_pool_create(arr, len(device_ids), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().mi355_jpeg_pool_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workers(self):
+        return lib().mi355_jpeg_pool_workers(self._h)
+
+    def set_quality(self, quality):
+        _check(lib().mi355_jpeg_pool_set_quality(self._h, quality))
+
+    def set_quant(self, qlum, qchrom):
+        qlum = np.ascontiguousarray(qlum, np.uint32).reshape(64)
+        qchrom = np.ascontiguousarray(qchrom, np.uint32).reshape(64)
+        _check(lib().mi355_jpeg_pool_set_quant(self._h, qlum.ctypes.data, qchrom.ctypes.data))
+
+    def encode(self, frames, flags=F_DEFAULT, cap=None):
+        """frames: uint8 [n,H,W,3].  Returns (out [n,cap] uint8, bits list, seconds)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, H, W, _ = frames.shape
+        if cap is None:
+            cap = scan_bound(W, H)
+        out = np.zeros((n, cap), np.uint8)
+        bits = (C.c_uint64 * n)()
+        secs = C.c_double()
+        _check(lib().mi355_jpeg_pool_encode(self._h, frames.ctypes.data, W, H, n, flags, out.ctypes.data, cap,
+                                            bits, C.byref(secs)))
+        return out, [int(b) for b in bits], secs.value

@@ -302,8 +302,10 @@ struct WaveArena {
 // software-pipelined two symbols ahead.  Same bits as walk_ac().
 // ----------------------------------------------------------------------------
 constexpr uint32_t kSlotRows = 24;  // words per unit in the LDS slot; larger strings re-walk into global memory
-constexpr uint32_t kLut2Zrl = 15 * 64 + 32;  // (run 15, value 0): ZRL
-constexpr uint32_t kLut2Eob = 1 * 64 + 32;   // spare slot (run 1, value 0): EOB; (run 0, value 0) must stay 0
+// Symbol table layout [run][value + 32]: the value-0 column (index 32) is all zero (no-op for
+// exhausted lanes, whatever their run); the unused value -32 column carries ZRL and EOB.
+constexpr uint32_t kLut2Zrl = 15 * 64 + 0;
+constexpr uint32_t kLut2Eob = 0;
 
 // Left-aligned 32-bit bit packer.  e = symbol bits left-aligned | length (<= 27) in bits 4..0.
 // Every put stores the word being filled (a later put to the same word overwrites it).
@@ -358,7 +360,6 @@ __device__ __forceinline__ uint32_t symbol_slow(int v, uint32_t r, const uint32_
 
 struct WalkA {  // stage A result: position of a symbol + its value read in flight
     uint32_t pos;
-    bool valid;
     int v;
 };
 struct WalkB {  // stage B result: symbol entry read in flight
@@ -366,16 +367,17 @@ struct WalkB {  // stage B result: symbol entry read in flight
     uint32_t r;
     uint32_t zc;
     int v;
-    bool valid, fast;
+    bool fast;
 };
 
-// row: this lane's zig-zag row in LDS as int16; mask: non-zero positions 1..63.
+// row: this lane's zig-zag row in LDS as int16, with row[64] == 0 (sentinel); mask: non-zero
+// positions 1..63.  A lane that has run out of non-zeros keeps reading the sentinel: value 0
+// selects the all-zero column of the symbol table, i.e. a no-op put -- no validity bookkeeping.
 template <typename Store>
 __device__ __forceinline__ bool walk_nonzeros(const int16_t* row, uint64_t mask, const uint32_t* __restrict__ lut2,
                                               const uint32_t* __restrict__ act, Packer32<Store>& pk) {
     uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
-    uint32_t cnt = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
-    uint32_t maxcnt = cnt;
+    uint32_t maxcnt = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         uint32_t o = (uint32_t)__shfl_xor((int)maxcnt, d);
@@ -387,11 +389,10 @@ __device__ __forceinline__ bool walk_nonzeros(const int16_t* row, uint64_t mask,
 
     auto stageA = [&]() -> WalkA {
         WalkA a;
-        a.valid = (mlo | mhi) != 0u;
-        const uint32_t plo = (uint32_t)(__ffs((int)mlo) - 1);        // 0xFFFFFFFF when mlo == 0
-        const uint32_t phi = (uint32_t)(__ffs((int)mhi) - 1) + 32u;  // 31 (wrapped) when mhi == 0: only used if mlo == 0 too
-        uint32_t p = plo < phi ? plo : phi;
-        a.pos = a.valid ? p : 0u;
+        const uint32_t plo = (uint32_t)(__ffs((int)mlo) - 1);  // 0xFFFFFFFF when mlo == 0
+        uint32_t phi = (uint32_t)(__ffs((int)mhi) - 1);        // 0xFFFFFFFF when mhi == 0
+        phi = (phi < 32u ? phi : 32u) + 32u;                   // ... -> 64 = the sentinel slot
+        a.pos = plo < phi ? plo : phi;
         // clear the lowest set bit of the 64-bit mask
         const uint32_t nlo = mlo & (mlo - 1u);
         const uint32_t nhi = mlo ? mhi : (mhi & (mhi - 1u));
@@ -402,12 +403,11 @@ __device__ __forceinline__ bool walk_nonzeros(const int16_t* row, uint64_t mask,
     };
     auto stageB = [&](const WalkA& a) -> WalkB {
         WalkB b;
-        b.valid = a.valid;
         const uint32_t run = a.pos - prev - 1u;
-        prev = a.valid ? a.pos : prev;
-        b.v = a.valid ? a.v : 0;
-        b.r = a.valid ? (run & 15u) : 0u;
-        b.zc = a.valid ? (run >> 4) : 0u;
+        prev = a.pos;
+        b.v = a.v;
+        b.r = run & 15u;
+        b.zc = a.v != 0 ? (run >> 4) : 0u;
         b.fast = (uint32_t)(b.v + 31) <= 62u;
         const uint32_t idx = b.fast ? (b.r * 64u + (uint32_t)(b.v + 32)) : 32u;
         b.e_fast = lut2[idx];
@@ -416,7 +416,7 @@ __device__ __forceinline__ bool walk_nonzeros(const int16_t* row, uint64_t mask,
     auto stageC = [&](const WalkB& b) {
         uint32_t e = b.e_fast;
         if (!b.fast) e = symbol_slow(b.v, b.r, act);
-        ok = ok && !(b.valid && e == 0u);
+        ok = ok && !(b.v != 0 && e == 0u);
         if (b.zc) {  // (15,0) at every 16th zero before a later non-zero
             const uint32_t z = lut2[kLut2Zrl];
             for (uint32_t i = 0; i < b.zc; ++i) pk.put(z);
@@ -489,6 +489,7 @@ __global__ void __launch_bounds__(256, 2)
     for (uint32_t i = tid; i < 2048; i += 256) (&s_lut2[0][0])[i] = sp.lut2[i];
     (&s_qf[0][0][0])[tid] = sp.qconst_f[tid];
     if (tid < 32) s_dc[tid >> 4][tid & 15] = sp.lut[(tid >> 4) * 256 + (tid & 15)];
+    s_tbuf[lane * 33 + 32] = 0;  // sentinel after zig-zag position 63 of every row (never written again)
     // A fragments of digits 1..4 stay in registers; digit 0 only matters for the (rare)
     // second look and is fetched on demand.
     v4i A[4][kScreenLimbs - 1];

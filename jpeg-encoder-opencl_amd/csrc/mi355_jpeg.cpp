@@ -228,8 +228,8 @@ int upload_tables(mi355_jpeg_ctx* c) {
     HIP_TRY(hipMemcpy(c->d_qconst_f, qf, sizeof qf, hipMemcpyHostToDevice));
     // Whole-symbol tables of the screened pipeline's unit walk: for run r and value v (|v| <= 31)
     // the Huffman code of (r, size(v)) followed by v's value bits, left-aligned in 32 bits, with
-    // the total length in bits 4..0; 0 = the reference has no code.  (15, 0) = ZRL; the spare
-    // slot (1, 0) carries EOB; (0, 0) stays 0 (a no-op for exhausted lanes).
+    // the total length in bits 4..0; 0 = the reference has no code.  The value-0 column stays 0 (a
+    // no-op for lanes that ran out of non-zeros); ZRL and EOB live in the unused value -32 column.
     std::vector<uint32_t> lut2(2 * 1024, 0u);
     for (int ct = 0; ct < 2; ++ct) {
         const mi355_huff_table& t = c->huff[2 + ct];
@@ -244,8 +244,8 @@ int upload_tables(mi355_jpeg_ctx* c) {
                 uint32_t vb = (uint32_t)(v < 0 ? v + (1 << size) - 1 : v);
                 lut2[ct * 1024 + r * 64 + v + 32] = entry((t.code[rs] << size) | vb, t.len[rs] + size);
             }
-        lut2[ct * 1024 + 15 * 64 + 32] = entry(t.code[0xF0], t.len[0xF0]);
-        lut2[ct * 1024 + 1 * 64 + 32] = entry(t.code[0x00], t.len[0x00]);
+        lut2[ct * 1024 + 15 * 64 + 0] = entry(t.code[0xF0], t.len[0xF0]);  // ZRL in the unused value -32 column
+        lut2[ct * 1024 + 0] = entry(t.code[0x00], t.len[0x00]);            // EOB likewise; column 32 (value 0) stays 0
     }
     HIP_TRY(hipMemcpy(c->d_lut2, lut2.data(), lut2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return MI355_OK;
@@ -873,6 +873,218 @@ int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, ui
     w.w(0xFFD9);
     *out_len = w.n;
     return w.n > cap ? MI355_E_CAPACITY : MI355_OK;
+}
+
+// ---- multi-GPU batch driver ----------------------------------------------------------
+//
+// Frames are independent (DC predictors start at 0 per frame, utils.cpp:665), so a batch
+// shards over GPUs with no exchange at all.  Worker w owns frames [lo_w, hi_w) and moves them
+// through its GPU in chunks: three streams, double-buffered device memory, user memory
+// registered with HIP for the duration of the call so that H2D / D2H are true DMA.
+
+}  // extern "C"
+
+#include <chrono>
+#include <thread>
+
+struct mi355_jpeg_pool {
+    std::vector<mi355_jpeg_ctx*> ctx;
+};
+
+namespace {
+
+struct PoolJob {
+    mi355_jpeg_ctx* c;
+    const uint8_t* rgb;
+    uint32_t W, H, lo, hi, flags;
+    uint8_t* out;
+    size_t out_stride;
+    uint64_t* bits;
+    int rc;
+};
+
+void pool_worker(PoolJob* j) {
+    j->rc = MI355_OK;
+    if (j->lo >= j->hi) return;
+    mi355_jpeg_ctx* c = j->c;
+    auto fail = [&](int rc) { j->rc = rc; };
+    if (hipSetDevice(c->device) != hipSuccess) return fail(MI355_E_NO_DEVICE);
+    const size_t fbytes = (size_t)j->W * j->H * 3;
+    size_t dstride = (j->out_stride + 3) & ~(size_t)3;
+    if (dstride < 8) dstride = 8;
+    // chunk: about 256 MB of input, at least 1 frame
+    uint32_t chunk = (uint32_t)((256u << 20) / fbytes);
+    if (chunk < 1) chunk = 1;
+    if (chunk > j->hi - j->lo) chunk = j->hi - j->lo;
+    uint8_t *d_in[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
+    uint64_t *d_bits[2] = {nullptr, nullptr}, *h_bits = nullptr;
+    hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    int rc = MI355_OK;
+    auto H = [&](hipError_t e) {
+        if (e != hipSuccess && rc == MI355_OK) rc = MI355_E_HIP - (int)e;
+        return e == hipSuccess;
+    };
+    for (int b = 0; b < 2 && rc == MI355_OK; ++b) {
+        H(hipMalloc((void**)&d_in[b], fbytes * chunk));
+        H(hipMalloc((void**)&d_out[b], dstride * chunk));
+        H(hipMalloc((void**)&d_bits[b], sizeof(uint64_t) * chunk));
+        H(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming));
+        H(hipEventCreateWithFlags(&ev_cmp[b], hipEventDisableTiming));
+        H(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming));
+    }
+    H(hipHostMalloc((void**)&h_bits, sizeof(uint64_t) * chunk * 2, hipHostMallocDefault));
+    H(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+    H(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking));
+    H(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+    // register the caller's slabs so that the copies are asynchronous DMA (best effort)
+    const uint8_t* in_lo = j->rgb + (size_t)j->lo * fbytes;
+    uint8_t* out_lo = j->out + (size_t)j->lo * j->out_stride;
+    const bool reg_in = hipHostRegister((void*)in_lo, fbytes * (j->hi - j->lo), hipHostRegisterDefault) == hipSuccess;
+    const bool reg_out =
+        hipHostRegister((void*)out_lo, j->out_stride * (j->hi - j->lo), hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+
+    const uint32_t nchunks = (j->hi - j->lo + chunk - 1) / chunk;
+    auto frames_of = [&](uint32_t k) { uint32_t a = j->lo + k * chunk; return (a + chunk <= j->hi ? chunk : j->hi - a); };
+    auto drain = [&](uint32_t k) {  // chunk k is encoded: fetch its bit counts, then its bytes
+        const int b = (int)(k & 1);
+        const uint32_t a = j->lo + k * chunk, nf = frames_of(k);
+        H(hipStreamWaitEvent(s_out, ev_cmp[b], 0));
+        H(hipMemcpyAsync(h_bits + (size_t)b * chunk, d_bits[b], sizeof(uint64_t) * nf, hipMemcpyDeviceToHost, s_out));
+        H(hipStreamSynchronize(s_out));
+        for (uint32_t f = 0; f < nf && rc == MI355_OK; ++f) {
+            const uint64_t nb = h_bits[(size_t)b * chunk + f];
+            j->bits[a + f] = nb;
+            const size_t bytes = (size_t)((nb + 7) / 8);
+            if (bytes > j->out_stride) {
+                rc = MI355_E_CAPACITY;
+                break;
+            }
+            H(hipMemcpyAsync(j->out + (size_t)(a + f) * j->out_stride, d_out[b] + (size_t)f * dstride, bytes,
+                             hipMemcpyDeviceToHost, s_out));
+        }
+        H(hipEventRecord(ev_out[b], s_out));
+    };
+    for (uint32_t k = 0; k < nchunks && rc == MI355_OK; ++k) {
+        const int b = (int)(k & 1);
+        const uint32_t a = j->lo + k * chunk, nf = frames_of(k);
+        if (k >= 2) {  // buffers of chunk k-2 must be fully drained before reuse
+            H(hipStreamWaitEvent(s_in, ev_out[b], 0));
+            H(hipStreamWaitEvent(s_cmp, ev_out[b], 0));
+        }
+        H(hipMemcpyAsync(d_in[b], j->rgb + (size_t)a * fbytes, fbytes * nf, hipMemcpyHostToDevice, s_in));
+        H(hipEventRecord(ev_in[b], s_in));
+        H(hipStreamWaitEvent(s_cmp, ev_in[b], 0));
+        if (rc == MI355_OK) {
+            int e = mi355_jpeg_encode_scan_device(c, d_in[b], j->W, j->H, nf, j->flags, d_out[b], dstride, d_bits[b], s_cmp);
+            if (e) rc = e;
+        }
+        H(hipEventRecord(ev_cmp[b], s_cmp));
+        if (k >= 1 && rc == MI355_OK) drain(k - 1);  // overlaps the encode of chunk k
+    }
+    if (rc == MI355_OK) drain(nchunks - 1);
+    if (s_out) (void)hipStreamSynchronize(s_out);
+    if (rc == MI355_OK) {
+        int e = mi355_jpeg_sync(c, s_cmp);
+        if (e) rc = e;
+    } else if (s_cmp) {
+        (void)hipStreamSynchronize(s_cmp);
+    }
+    if (reg_in) (void)hipHostUnregister((void*)in_lo);
+    if (reg_out) (void)hipHostUnregister((void*)out_lo);
+    for (int b = 0; b < 2; ++b) {
+        if (d_in[b]) (void)hipFree(d_in[b]);
+        if (d_out[b]) (void)hipFree(d_out[b]);
+        if (d_bits[b]) (void)hipFree(d_bits[b]);
+        if (ev_in[b]) (void)hipEventDestroy(ev_in[b]);
+        if (ev_cmp[b]) (void)hipEventDestroy(ev_cmp[b]);
+        if (ev_out[b]) (void)hipEventDestroy(ev_out[b]);
+    }
+    if (h_bits) (void)hipHostFree(h_bits);
+    if (s_in) (void)hipStreamDestroy(s_in);
+    if (s_cmp) (void)hipStreamDestroy(s_cmp);
+    if (s_out) (void)hipStreamDestroy(s_out);
+    fail(rc);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355_jpeg_pool_create(const int* device_ids, int n_workers, mi355_jpeg_pool** out) {
+    if (!out) return MI355_E_ARG;
+    *out = nullptr;
+    int ndev = mi355_jpeg_device_count();
+    if (ndev <= 0) return MI355_E_NO_DEVICE;
+    std::vector<int> ids;
+    if (device_ids) {
+        if (n_workers <= 0) return MI355_E_ARG;
+        ids.assign(device_ids, device_ids + n_workers);
+    } else {
+        for (int d = 0; d < ndev; ++d) ids.push_back(d);
+    }
+    mi355_jpeg_pool* p = new (std::nothrow) mi355_jpeg_pool();
+    if (!p) return MI355_E_ALLOC;
+    for (int id : ids) {
+        mi355_jpeg_ctx* c = nullptr;
+        int e = mi355_jpeg_create(id, &c);
+        if (e) {
+            mi355_jpeg_pool_destroy(p);
+            return e;
+        }
+        p->ctx.push_back(c);
+    }
+    *out = p;
+    return MI355_OK;
+}
+
+void mi355_jpeg_pool_destroy(mi355_jpeg_pool* p) {
+    if (!p) return;
+    for (auto* c : p->ctx) mi355_jpeg_destroy(c);
+    delete p;
+}
+
+int mi355_jpeg_pool_workers(mi355_jpeg_pool* p) { return p ? (int)p->ctx.size() : 0; }
+
+int mi355_jpeg_pool_set_quant(mi355_jpeg_pool* p, const uint32_t qlum[64], const uint32_t qchrom[64]) {
+    if (!p) return MI355_E_ARG;
+    for (auto* c : p->ctx) {
+        int e = mi355_jpeg_set_quant(c, qlum, qchrom);
+        if (e) return e;
+    }
+    return MI355_OK;
+}
+
+int mi355_jpeg_pool_set_quality(mi355_jpeg_pool* p, int quality) {
+    if (!p) return MI355_E_ARG;
+    for (auto* c : p->ctx) {
+        int e = mi355_jpeg_set_quality(c, quality);
+        if (e) return e;
+    }
+    return MI355_OK;
+}
+
+int mi355_jpeg_pool_encode(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t n_frames,
+                           uint32_t flags, uint8_t* out, size_t out_stride, uint64_t* bits, double* seconds) {
+    if (!p || p->ctx.empty() || !rgb || !out || !bits || n_frames == 0) return MI355_E_ARG;
+    Geom g;
+    int e = make_geom(W, H, flags, nullptr, &g);
+    if (e) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t nw = (uint32_t)p->ctx.size();
+    std::vector<PoolJob> jobs(nw);
+    std::vector<std::thread> th;
+    for (uint32_t w = 0; w < nw; ++w) {
+        const uint32_t lo = (uint32_t)((uint64_t)n_frames * w / nw), hi = (uint32_t)((uint64_t)n_frames * (w + 1) / nw);
+        jobs[w] = PoolJob{p->ctx[w], rgb, W, H, lo, hi, flags, out, out_stride, bits, MI355_OK};
+        th.emplace_back(pool_worker, &jobs[w]);
+    }
+    for (auto& t : th) t.join();
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (auto& jb : jobs)
+        if (jb.rc) return jb.rc;
+    return MI355_OK;
 }
 
 // ---- measurement ---------------------------------------------------------------

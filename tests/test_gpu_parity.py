@@ -425,3 +425,29 @@ def test_config3_batch_of_1080p_frames_q75(jpeg, enc):
     for f in (1, 17, 47):
         o = ol.oracle_encode(frames[f], ql, qc, True)
         assert nb[f] == o.n_bits and np.array_equal(bits[f], o.bits)
+
+
+def test_pool_shards_frames_over_workers(jpeg):
+    """Multi-GPU batch driver on this one-GPU box: three workers on device 0 (the same code
+    path as one worker per GPU), ragged split, chunked double-buffered pipeline."""
+    n, W, H = 23, 640, 360
+    frames = np.stack([ol.lcg_frame(W, H, 100 + f) for f in range(n)])
+    pool = jpeg.Pool([0, 0, 0])
+    assert pool.workers == 3
+    pool.set_quality(75)
+    out, bits, secs = pool.encode(frames, cap=1 << 20)
+    pool.close()
+    assert secs > 0
+    ql, qc = ol.quant_tables(75)
+    for f in range(n):
+        o = ol.oracle_encode(frames[f], ql, qc, True)
+        assert bits[f] == o.n_bits, f
+        assert np.array_equal(out[f, :(o.n_bits + 7) // 8], o.bits), f
+    # single worker, chunked (chunk < batch): 4K frames, 256 MB chunks -> 10 frames per chunk
+    pool = jpeg.Pool([0])
+    frames = np.stack([ol.lcg_frame(3840, 2160, 1 + (f % 3)) for f in range(12)])
+    out, bits, secs = pool.encode(frames, cap=6 << 20)
+    pool.close()
+    assert bits[0] == bits[3] == bits[9] == 38227880 and bits[1] == bits[10]
+    assert ascii_sha(out[0, :(bits[0] + 7) // 8], bits[0]) == "6a4a20a6412d6e3bfd878e09875156170ff80a74d7c10c04b52a425e7dbcf009"
+    assert np.array_equal(out[0], out[9]) and np.array_equal(out[1], out[10])
