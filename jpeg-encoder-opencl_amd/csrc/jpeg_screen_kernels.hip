@@ -31,6 +31,8 @@ namespace mi355 {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+// the zig-zag rows are written as packed uint32 pairs and read back as int16: tell TBAA
+typedef int16_t __attribute__((may_alias)) i16a;
 
 constexpr uint32_t kSlotWordsFull = 54;  // worst case 63*(17+10)+4 = 1705 bits
 
@@ -374,7 +376,7 @@ struct WalkB {  // stage B result: symbol entry read in flight
 // positions 1..63.  A lane that has run out of non-zeros keeps reading the sentinel: value 0
 // selects the all-zero column of the symbol table, i.e. a no-op put -- no validity bookkeeping.
 template <typename Store>
-__device__ __forceinline__ bool walk_nonzeros(const int16_t* row, uint64_t mask, const uint32_t* __restrict__ lut2,
+__device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, const uint32_t* __restrict__ lut2,
                                               const uint32_t* __restrict__ act, Packer32<Store>& pk) {
     uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
     uint32_t maxcnt = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
@@ -720,7 +722,7 @@ __global__ void __launch_bounds__(256, 2)
         const uint32_t b = tile * 64 + lane;
         const bool active = b < g.N;
         bool flagged = s_flag[lane] != 0;
-        const int16_t* row16 = reinterpret_cast<const int16_t*>(&s_tbuf[lane * 33]);
+        const i16a* row16 = reinterpret_cast<const i16a*>(&s_tbuf[lane * 33]);
         const uint64_t mask = ((uint64_t)s_mhi[lane] << 32 | s_mlo[lane]) & ~1ull;
         const int dc = (int)row16[0];
 
