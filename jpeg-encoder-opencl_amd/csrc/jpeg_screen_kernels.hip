@@ -258,16 +258,6 @@ __device__ __forceinline__ bool walk_ac_batched(const uint32_t (&c)[32], const u
 
 __device__ __forceinline__ int meta_dc(uint32_t y) { return (int)(int16_t)(y & 0xffffu); }
 
-// wave-wide inclusive prefix sum
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if ((int)lane >= d) v += t;
-    }
-    return v;
-}
-
 // Arena allocation for one wave.  Every persistent wave owns a private region and bumps a
 // private pointer (no atomics: a returning atomic on one address saturates at ~88 per
 // microsecond chip-wide, far below the wave-tile rate).  A wave whose region is full takes
@@ -360,6 +350,36 @@ __device__ __forceinline__ uint32_t symbol_slow(int v, uint32_t r, const uint32_
     return (m << (32u - t)) | t;
 }
 
+// Wave-wide inclusive prefix sum / maximum with DPP row shifts and row broadcasts (6 VALU
+// instructions, no LDS round trips like __shfl).  Lane 63 ends up with the reduction.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_src(uint32_t v) {
+    // lanes without a valid source (or outside ROW_MASK) read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/) {
+    v += dpp_src<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_src<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_src<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_src<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_src<0x142, 0xa>(v);  // row_bcast:15 into rows 1, 3
+    v += dpp_src<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {  // uniform result
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63);
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {  // uniform result
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, dpp_src<0x111, 0xf>(v));
+    v = mx(v, dpp_src<0x112, 0xf>(v));
+    v = mx(v, dpp_src<0x114, 0xf>(v));
+    v = mx(v, dpp_src<0x118, 0xf>(v));
+    v = mx(v, dpp_src<0x142, 0xa>(v));
+    v = mx(v, dpp_src<0x143, 0xc>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 struct WalkA {  // stage A result: position of a symbol + its value read in flight
     uint32_t pos;
     int v;
@@ -375,17 +395,13 @@ struct WalkB {  // stage B result: symbol entry read in flight
 // row: this lane's zig-zag row in LDS as int16, with row[64] == 0 (sentinel); mask: non-zero
 // positions 1..63.  A lane that has run out of non-zeros keeps reading the sentinel: value 0
 // selects the all-zero column of the symbol table, i.e. a no-op put -- no validity bookkeeping.
+// maxcnt: wave-uniform upper bound of the lanes' non-zero counts (wave_max of popcount(mask),
+// formed by the caller with all lanes active: DPP reductions need the full wave).
 template <typename Store>
 __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, const uint32_t* __restrict__ lut2,
-                                              const uint32_t* __restrict__ act, Packer32<Store>& pk) {
+                                              const uint32_t* __restrict__ act, Packer32<Store>& pk,
+                                              const uint32_t maxcnt) {
     uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
-    uint32_t maxcnt = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)maxcnt, d);
-        maxcnt = o > maxcnt ? o : maxcnt;
-    }
-    maxcnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxcnt);
     uint32_t prev = 0;
     bool ok = true;
 
@@ -733,7 +749,8 @@ __global__ void __launch_bounds__(256, 2)
         }
 
         Packer32<StoreLds> pkr(StoreLds{&s_slot[lane]});
-        bool ok = walk_nonzeros(row16, mask, s_lut2[ct], s_act[ct], pkr);
+        const uint32_t maxcnt = wave_max((uint32_t)__popcll(mask));
+        bool ok = walk_nonzeros(row16, mask, s_lut2[ct], s_act[ct], pkr, maxcnt);
         const uint32_t aclen = pkr.bits();
         uint32_t nw = pkr.words();
         STAMP(2);
@@ -761,8 +778,7 @@ __global__ void __launch_bounds__(256, 2)
                 } else {
                     sm = sample_generic_int(f, g, (int)chan, avg, pbx * 8 + (lane & 7), pby * 8 + (lane >> 3));
                 }
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) sm += (uint32_t)__shfl_xor((int)sm, d);
+                sm = wave_sum(sm);
                 const double pc0 = (double)((int)sm - 8192) * kScale00;
                 pred0 = (int)__builtin_round(pc0 / sp.qd[ct * 64]);
             }
@@ -773,8 +789,7 @@ __global__ void __launch_bounds__(256, 2)
             const bool dc_ok = put_dc(dc - pred, s_dc[ct], count);
             if (!dc_ok && active) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
             if (!active || flagged) ubits = 0;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) ubits += (uint32_t)__shfl_xor((int)ubits, d);
+            ubits = wave_sum(ubits);
             if (lane == 0 && ubits) atomicAdd(&sp.tile_bits[(size_t)frame * g.tiles + tile], ubits);
         }
 
@@ -797,7 +812,7 @@ __global__ void __launch_bounds__(256, 2)
             if (__any(oversize && nw)) {  // rare: string longer than the LDS slot: walk again, straight to memory
                 if (oversize && nw) {
                     Packer32<StoreGlobal> pg(StoreGlobal{sp.arena + off});
-                    (void)walk_nonzeros(row16, mask, s_lut2[ct], s_act[ct], pg);
+                    (void)walk_nonzeros(row16, mask, s_lut2[ct], s_act[ct], pg, maxcnt);
                 }
             }
         }
