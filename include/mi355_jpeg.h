@@ -153,6 +153,18 @@ int mi355_jpeg_probe_unit_bits(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t
 int mi355_jpeg_entropy_only(mi355_jpeg_ctx *ctx, const int16_t *zigzag, uint32_t n_blocks,
                             uint8_t *out, size_t cap, uint64_t *bits);
 
+/* ---- either side of the path ---------------------------------
+ * Pinned synthetic input, generated in place on the device: frame f gets the
+ * bytes s_{k+1} >> 24 of the LCG s <- s*1664525 + 1013904223 with s_0 = seed0 + f. */
+int mi355_jpeg_synth_lcg_device(mi355_jpeg_ctx *ctx, void *d_dst, size_t frame_bytes, uint32_t n_frames,
+                                uint32_t seed0, void *stream);
+/* JFIF byte stuffing of ONE frame's scan on the device: d_scan / d_bits as written by
+ * mi355_jpeg_encode_scan_device; the last partial byte is padded with 1s and every 0xFF is
+ * followed by 0x00.  d_out_len (device uint64) receives the stuffed length.  max_scan_bytes
+ * bounds ceil(bits/8) (e.g. the scan buffer's stride). */
+int mi355_jpeg_stuff_device(mi355_jpeg_ctx *ctx, const void *d_scan, const uint64_t *d_bits, size_t max_scan_bytes,
+                            void *d_out, size_t cap, uint64_t *d_out_len, void *stream);
+
 /* ---- multi-GPU batch driver (host frames in, host scans out) -------------
  * The production shape of BASELINE configs[3]: a batch of independent frames sharded
  * across the GPUs of one node, no collective.  One worker thread + one context per

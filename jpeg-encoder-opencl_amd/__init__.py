@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "mi355_jpeg_encode_scan", "mi355_jpeg_encode_scan_device", "mi355_jpeg_sync", "mi355_jpeg_encode_jfif",
     "mi355_jpeg_probe_samples", "mi355_jpeg_probe_coefficients", "mi355_jpeg_probe_unit_bits",
     "mi355_jpeg_entropy_only", "mi355_jpeg_set_profiling", "mi355_jpeg_last_timings",
-    "mi355_jpeg_profile_summary", "mi355_jpeg_pool_create", "mi355_jpeg_pool_destroy", "mi355_jpeg_pool_workers",
+    "mi355_jpeg_profile_summary", "mi355_jpeg_synth_lcg_device", "mi355_jpeg_stuff_device", "mi355_jpeg_pool_create", "mi355_jpeg_pool_destroy", "mi355_jpeg_pool_workers",
     "mi355_jpeg_pool_set_quant", "mi355_jpeg_pool_set_quality", "mi355_jpeg_pool_encode",
 ]
 
@@ -103,6 +103,8 @@ def lib():
         L.mi355_jpeg_set_profiling.argtypes = [vp, C.c_int]
         L.mi355_jpeg_last_timings.argtypes = [vp, C.POINTER(Timings)]
         L.mi355_jpeg_profile_summary.argtypes = [vp, C.POINTER(Timings), C.POINTER(u32)]
+        L.mi355_jpeg_synth_lcg_device.argtypes = [vp, vp, sz, u32, u32, vp]
+        L.mi355_jpeg_stuff_device.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp]
         L.mi355_jpeg_pool_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
         L.mi355_jpeg_pool_destroy.argtypes = [vp]
         L.mi355_jpeg_pool_destroy.restype = None
@@ -216,6 +218,14 @@ class Encoder:
 
     def sync(self, stream=0):
         _check(lib().mi355_jpeg_sync(self._h, stream))
+
+    # ---- either side of the path
+    def synth_lcg_device(self, d_dst, frame_bytes, n_frames, seed0, stream=0):
+        """Fill device memory with the pinned LCG frames (seed = seed0 + frame)."""
+        _check(lib().mi355_jpeg_synth_lcg_device(self._h, d_dst, frame_bytes, n_frames, seed0, stream))
+
+    def stuff_device(self, d_scan, d_bits, max_scan_bytes, d_out, cap, d_out_len, stream=0):
+        _check(lib().mi355_jpeg_stuff_device(self._h, d_scan, d_bits, max_scan_bytes, d_out, cap, d_out_len, stream))
 
     # ---- stage probes
     def probe_samples(self, rgb, flags=F_DEFAULT):

@@ -147,6 +147,10 @@ struct mi355_jpeg_ctx {
     uint32_t screen_waves = 2048;   // persistent single-wave workgroups of k_screen_encode
     int transform_mode = 2;         // 0 exact fp64 chain (unrolled), 1 exact (looped), 2 screened MFMA + exact fix-up
     uint32_t emit_lds_words = 4096;
+    uint32_t* d_stuff_counts = nullptr;  // byte stuffing scratch
+    size_t stuff_cap = 0;
+    uint64_t* d_stuff_offs = nullptr;
+    size_t stuff_offs_cap = 0;
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
     int profiling = 0;              // 0 off, 1 all stages, 2 transform only
     std::vector<EventSet> ev_pool;  // grown on demand, reused after a reset
@@ -532,7 +536,8 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
                     c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
-                    c->d_counters, c->d_meta,     c->d_arena,  c->d_fixlist, c->d_lut2,     c->d_qconst_f};
+                    c->d_counters, c->d_meta,     c->d_arena,  c->d_fixlist, c->d_lut2,     c->d_qconst_f,
+                    c->d_stuff_counts, c->d_stuff_offs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& es : c->ev_pool)
@@ -828,21 +833,14 @@ void dht_segment(Writer& w, int cls_id, const mi355_huff_table& t) {
 int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
                            uint8_t* out, size_t cap, size_t* out_len) {
     if (!c || !rgb || !out || !out_len) return MI355_E_ARG;
-    size_t bound = mi355_jpeg_scan_bound(W, H);
-    std::vector<uint8_t> scan;
-    uint64_t nbits = 0;
-    // try a modest buffer first (8 bits/px), fall back to the worst-case bound
-    size_t guess = (size_t)W * H + 4096;
-    if (guess > bound) guess = bound;
-    scan.resize(guess);
-    int e = mi355_jpeg_encode_scan(c, rgb, W, H, 1, flags, scan.data(), scan.size(), &nbits);
-    if (e == MI355_E_CAPACITY) {
-        scan.resize(bound);
-        e = mi355_jpeg_encode_scan(c, rgb, W, H, 1, flags, scan.data(), scan.size(), &nbits);
-    }
+    Geom g;
+    int e = make_geom(W, H, flags, nullptr, &g);
     if (e) return e;
+    HIP_TRY(hipSetDevice(c->device));
+    // header (host): SOI, APP0, DQT x2, SOF0 (H1V1 x3), DHT x4, SOS
     static const uint8_t zz[64] = MI355_ZIGZAG_TABLE;
-    Writer w{out, 0, cap};
+    std::vector<uint8_t> hdr(1024);
+    Writer w{hdr.data(), 0, hdr.size()};
     w.w(0xFFD8);
     w.w(0xFFE0), w.w(16);
     w.b('J'), w.b('F'), w.b('I'), w.b('F'), w.b(0);
@@ -863,16 +861,65 @@ int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, ui
     w.w(0xFFDA), w.w(12), w.b(3);
     w.b(1), w.b(0x00), w.b(2), w.b(0x11), w.b(3), w.b(0x11);
     w.b(0), w.b(63), w.b(0);
-    size_t nb = (size_t)((nbits + 7) / 8);
-    for (size_t i = 0; i < nb; ++i) {
-        unsigned b = scan[i];
-        if (i == nb - 1 && (nbits & 7)) b |= 0xFFu >> (nbits & 7);  // pad with 1s
-        w.b(b);
-        if (b == 0xFF) w.b(0);
+    const size_t hlen = w.n;
+    if (hlen + 2 > cap) return MI355_E_CAPACITY;
+
+    // scan on the device, stuffed on the device (k_stuff_*), one copy back
+    size_t scan_cap = (size_t)W * H + 4096;  // 8 bits per pixel first; the worst-case bound on overflow
+    const size_t bound = mi355_jpeg_scan_bound(W, H);
+    if (scan_cap > bound) scan_cap = bound;
+    if ((e = ensure(c->d_in, c->in_cap, (size_t)g.frame_stride))) return e;
+    if ((e = ensure(c->d_bits, c->bits_cap, (size_t)2))) return e;
+    HIP_TRY(hipMemcpy(c->d_in, rgb, g.frame_stride, hipMemcpyHostToDevice));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        scan_cap = (scan_cap + 3) & ~(size_t)3;
+        const size_t stuffed_cap = 2 * scan_cap + 16;
+        if ((e = ensure(c->d_out, c->out_cap, scan_cap + stuffed_cap))) return e;
+        e = mi355_jpeg_encode_scan_device(c, c->d_in, W, H, 1, flags, c->d_out, scan_cap, c->d_bits, nullptr);
+        if (!e) e = mi355_jpeg_stuff_device(c, c->d_out, c->d_bits, scan_cap, c->d_out + scan_cap, stuffed_cap,
+                                            c->d_bits + 1, nullptr);
+        if (!e) e = mi355_jpeg_sync(c, nullptr);
+        if (e == MI355_E_CAPACITY && attempt == 0 && scan_cap < bound) {
+            scan_cap = bound;
+            continue;
+        }
+        if (e) return e;
+        uint64_t slen = 0;
+        HIP_TRY(hipMemcpy(&slen, c->d_bits + 1, sizeof slen, hipMemcpyDeviceToHost));
+        *out_len = hlen + (size_t)slen + 2;
+        if (*out_len > cap) return MI355_E_CAPACITY;
+        memcpy(out, hdr.data(), hlen);
+        HIP_TRY(hipMemcpy(out + hlen, c->d_out + scan_cap, (size_t)slen, hipMemcpyDeviceToHost));
+        out[hlen + slen] = 0xFF;
+        out[hlen + slen + 1] = 0xD9;
+        return MI355_OK;
     }
-    w.w(0xFFD9);
-    *out_len = w.n;
-    return w.n > cap ? MI355_E_CAPACITY : MI355_OK;
+    return MI355_E_CAPACITY;
+}
+
+// ---- either side of the path ------------------------------------------------------------
+
+int mi355_jpeg_synth_lcg_device(mi355_jpeg_ctx* c, void* d_dst, size_t frame_bytes, uint32_t n_frames, uint32_t seed0,
+                                void* stream) {
+    if (!c || !d_dst || frame_bytes == 0 || n_frames == 0 || n_frames > 65535u) return MI355_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_lcg_fill((uint8_t*)d_dst, frame_bytes, n_frames, seed0, (hipStream_t)stream));
+    return MI355_OK;
+}
+
+int mi355_jpeg_stuff_device(mi355_jpeg_ctx* c, const void* d_scan, const uint64_t* d_bits, size_t max_scan_bytes,
+                            void* d_out, size_t cap, uint64_t* d_out_len, void* stream) {
+    if (!c || !d_scan || !d_bits || !d_out || !d_out_len || max_scan_bytes == 0) return MI355_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t chunks = (max_scan_bytes + 4095) / 4096;
+    int e;
+    if ((e = ensure(c->d_stuff_counts, c->stuff_cap, chunks))) return e;
+    if ((e = ensure(c->d_stuff_offs, c->stuff_offs_cap, chunks + 1))) return e;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_stuff((const uint8_t*)d_scan, d_bits, max_scan_bytes, c->d_stuff_counts, c->d_stuff_offs,
+                         c->d_stuff_offs + chunks, (uint8_t*)d_out, cap, c->d_status, s));
+    HIP_TRY(hipMemcpyAsync(d_out_len, c->d_stuff_offs + chunks, sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+    return MI355_OK;
 }
 
 // ---- multi-GPU batch driver ----------------------------------------------------------

@@ -75,41 +75,67 @@ const std::vector<std::vector<std::string>> AC_LUMA_HUFF_CODES = ac_strings(2);
 const std::vector<std::vector<std::string>> AC_CHROMA_HUFF_CODES = ac_strings(3);
 
 // ---- PPM I/O --------------------------------------------------------------------------
-// Same accepted form as the reference reader (utils.cpp:11-65): "P6\n", optional '#'
-// lines, "<w> <h>\n", "255\n", raw RGB.  Unlike the reference the fread result is checked.
+// The reference reader (utils.cpp:11-65) takes exactly "P6\n", optional '#' lines, "<w> <h>\n",
+// "255\n", raster.  This one accepts every well-formed binary PPM header of maxval 255 (any
+// whitespace between tokens, '#' comments anywhere in the header, one whitespace byte before
+// the raster) and checks the raster length; same return convention: 0, or -1 + message on
+// stdout.  Reentrant (no strtok).
+namespace {
+// next header token; skips whitespace and comments.  Returns false at EOF.
+bool ppm_token(FILE* fp, char* tok, size_t cap) {
+    int ch = fgetc(fp);
+    for (;;) {
+        while (ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r' || ch == '\f' || ch == '\v') ch = fgetc(fp);
+        if (ch != '#') break;
+        while (ch != '\n' && ch != EOF) ch = fgetc(fp);
+    }
+    size_t n = 0;
+    while (ch != EOF && ch != ' ' && ch != '\t' && ch != '\n' && ch != '\r' && ch != '\f' && ch != '\v' && ch != '#') {
+        if (n + 1 < cap) tok[n++] = (char)ch;
+        ch = fgetc(fp);
+    }
+    tok[n] = 0;
+    if (ch == '#') {  // comment glued to a token: drop it up to the end of the line
+        while (ch != '\n' && ch != EOF) ch = fgetc(fp);
+    }
+    // the whitespace byte that ended the token is consumed (for the last token it is THE separator)
+    return n > 0;
+}
+}  // namespace
+
 int readPPMImage(const char* path, size_t* width, size_t* height, rgb_pixel_t** img) {
     FILE* fp = fopen(path, "rb");
     if (!fp) {
         std::cout << "Error opening the file" << std::endl;
         return -1;
     }
-    char line[128];
-    if (!fgets(line, sizeof line, fp)) {
+    char tok[32];
+    if (!ppm_token(fp, tok, sizeof tok)) {
         std::cout << "Error reading the file" << std::endl;
         fclose(fp);
         return -1;
     }
-    if (strcmp(line, "P6\n") != 0) {
+    if (strcmp(tok, "P6") != 0) {
         std::cout << "Invalid file format" << std::endl;
         fclose(fp);
         return -1;
     }
-    long w = 0, h = 0;
-    while (fgets(line, sizeof line, fp)) {
-        if (line[0] == '#') continue;
-        if (sscanf(line, "%ld %ld", &w, &h) != 2 || w <= 0 || h <= 0) {
+    long vals[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) {
+        char* end = nullptr;
+        if (!ppm_token(fp, tok, sizeof tok) || (vals[i] = strtol(tok, &end, 10), *end != 0) || vals[i] <= 0) {
             std::cout << "Invalid file format" << std::endl;
             fclose(fp);
             return -1;
         }
-        if (!fgets(line, sizeof line, fp) || atoi(line) != 255) {
-            std::cout << "Invalid maximum value" << std::endl;
-            fclose(fp);
-            return -1;
-        }
-        break;
     }
-    if (w <= 0 || h <= 0) {
+    if (vals[2] != 255) {
+        std::cout << "Invalid maximum value" << std::endl;
+        fclose(fp);
+        return -1;
+    }
+    const long w = vals[0], h = vals[1];
+    if (w > 65535 || h > 65535) {
         std::cout << "Invalid file format" << std::endl;
         fclose(fp);
         return -1;

@@ -451,3 +451,106 @@ def test_pool_shards_frames_over_workers(jpeg):
     assert bits[0] == bits[3] == bits[9] == 38227880 and bits[1] == bits[10]
     assert ascii_sha(out[0, :(bits[0] + 7) // 8], bits[0]) == "6a4a20a6412d6e3bfd878e09875156170ff80a74d7c10c04b52a425e7dbcf009"
     assert np.array_equal(out[0], out[9]) and np.array_equal(out[1], out[10])
+
+
+def test_randomised_parity_sweep(jpeg, enc):
+    """80 random cases (size incl. ragged / tiny / wide, quality, chroma averaging on/off,
+    content: noise, smooth, flat, two-level, low-amplitude) against the oracle: scan bits
+    and per-unit bit counts."""
+    rng = np.random.default_rng(20261004)
+    for it in range(80):
+        W = int(rng.choice([8, 16, 24, 40, 64, 100, 127, 255, 256, 320, 511, 640, 1000]))
+        H = int(rng.choice([8, 9, 16, 31, 48, 64, 100, 129, 240]))
+        if (W + 7) // 8 * 8 - W > W or (H + 7) // 8 * 8 - H > H:
+            continue
+        kind = it % 5
+        if kind == 0:
+            rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        elif kind == 1:
+            yy, xx = np.mgrid[0:H, 0:W]
+            base = 128 + 100 * np.sin(xx / 17.0) * np.cos(yy / 11.0)
+            rgb = np.clip(base[..., None] + rng.normal(0, 3, (H, W, 3)), 0, 255).astype(np.uint8)
+        elif kind == 2:
+            rgb = np.full((H, W, 3), rng.integers(0, 256, 3), np.uint8)
+        elif kind == 3:
+            rgb = (rng.integers(0, 2, (H, W, 1)) * rng.integers(100, 256)).astype(np.uint8).repeat(3, 2)
+        else:
+            rgb = (120 + rng.integers(0, 6, (H, W, 3))).astype(np.uint8)
+        q = int(rng.choice([5, 25, 50, 50, 75, 90, 97]))
+        cds = bool(rng.integers(0, 2))
+        ql, qc = set_quality(enc, q)
+        try:
+            o = ol.oracle_encode(rgb, ql, qc, cds, KEEP)
+        except RuntimeError:  # a category outside the reference's tables: both sides must refuse
+            with pytest.raises(jpeg.JpegError):
+                enc.encode_scan(rgb, jpeg.F_CDS if cds else 0)
+            continue
+        flags = jpeg.F_CDS if cds else 0
+        bits, nb = enc.encode_scan(rgb, flags)
+        assert nb[0] == o.n_bits, (it, W, H, q, cds, kind)
+        assert np.array_equal(bits[0], o.bits), (it, W, H, q, cds, kind)
+        if it % 4 == 0:
+            assert np.array_equal(enc.probe_unit_bits(rgb, flags), o.unit_bits), (it, W, H, q, cds, kind)
+
+
+def test_two_contexts_two_threads(jpeg):
+    """Contexts are independent: two host threads, each with its own context and stream on
+    the same GPU, encode different batches concurrently."""
+    import threading
+    frames = [np.stack([ol.lcg_frame(512, 256, 40 + 10 * t + f) for f in range(6)]) for t in range(2)]
+    results = [None, None]
+
+    def work(t):
+        e = jpeg.Encoder(0)
+        e.set_quality(50 if t == 0 else 90)
+        out = []
+        for rep in range(5):
+            out = e.encode_scan(frames[t], jpeg.F_CDS)
+        results[t] = out
+        e.close()
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for t in range(2):
+        ql, qc = ol.quant_tables(50 if t == 0 else 90)
+        bits, nb = results[t]
+        for f in range(6):
+            o = ol.oracle_encode(frames[t][f], ql, qc, True)
+            assert nb[f] == o.n_bits and np.array_equal(bits[f], o.bits), (t, f)
+
+
+def test_device_lcg_generator_and_stuffing(jpeg, enc):
+    """The on-device synthetic-input generator equals the pinned LCG definition, and the
+    device byte-stuffing kernel equals the framing rule (pad with 1s, 0xFF -> 0xFF00)."""
+    import torch
+    W, H, n = 200, 37, 3
+    fb = W * H * 3
+    d = torch.zeros(n * fb, dtype=torch.uint8, device="cuda")
+    enc.synth_lcg_device(d.data_ptr(), fb, n, 5)
+    enc.sync()
+    got = d.cpu().numpy().reshape(n, H, W, 3)
+    for f in range(n):
+        assert np.array_equal(got[f], ol.lcg_frame(W, H, 5 + f))
+    # stuffing: a scan full of 0xFF runs, odd bit count
+    rng = np.random.default_rng(3)
+    scan = rng.choice(np.array([0xFF, 0xFF, 0x00, 0x7F, 0xFE], np.uint8), 100003)
+    nbits = scan.size * 8 - 5
+    d_scan = torch.from_numpy(scan).cuda()
+    d_bits = torch.tensor([nbits, 0], dtype=torch.int64, device="cuda")
+    d_out = torch.zeros(2 * scan.size + 16, dtype=torch.uint8, device="cuda")
+    enc.stuff_device(d_scan.data_ptr(), d_bits.data_ptr(), scan.size, d_out.data_ptr(), d_out.numel(),
+                     d_bits.data_ptr() + 8)
+    enc.sync()
+    ref = bytearray()
+    for i, b in enumerate(scan.tolist()):
+        if i == scan.size - 1:
+            b |= 0xFF >> (nbits & 7)
+        ref.append(b)
+        if b == 0xFF:
+            ref.append(0)
+    n_out = int(d_bits[1])
+    assert n_out == len(ref)
+    assert d_out[:n_out].cpu().numpy().tobytes() == bytes(ref)

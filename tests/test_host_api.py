@@ -71,3 +71,26 @@ def test_cli_ppm_to_jpg(tmp_path):
     assert open(out, "rb").read() == ol.jfif_frame(o.bits, o.n_bits, rgb.shape[1], rgb.shape[0], ql, qc)
     assert len(open(bits).read()) == 307829
     assert subprocess.call([CLI, "/nonexistent.ppm", out]) == 1
+
+
+def test_ppm_reader_accepts_wellformed_headers(tmp_path):
+    """No GPU needed: the host reader takes the reference's strict 3-line form and every other
+    well-formed P6/255 header (comments, arbitrary whitespace), and rejects bad input with -1
+    (exit code 1 of the CLI) instead of reading garbage."""
+    subprocess.check_call(["make", "-s", "-C", PKG, "all", "host"])
+    raster = bytes(range(48)) * 4  # 8x8x3
+    good = [b"P6\n8 8\n255\n", b"P6\n# a comment\n8 8\n255\n", b"P6 8 8 255\n", b"P6\n8\n8\n255\n",
+            b"P6\t8  8 # trailing comment\n255\n", b"P6\r\n8 8\r\n255\n"]
+    bad = [b"P5\n8 8\n255\n", b"P6\n8 8\n65535\n", b"P6\n8 x\n255\n", b"P6\n0 8\n255\n", b"P6\n8 8\n"]
+    for i, hdr in enumerate(good + bad):
+        path = tmp_path / ("t%d.ppm" % i)
+        path.write_bytes(hdr + raster)
+        out = subprocess.run([CLI, str(path), str(tmp_path / "o.jpg")], capture_output=True, text=True)
+        if i < len(good):
+            assert "Image %s: 8 x 8" % path in out.stdout, (hdr, out.stdout)
+        else:
+            assert out.returncode == 1 and "Image" not in out.stdout, (hdr, out.stdout)
+    short = tmp_path / "short.ppm"
+    short.write_bytes(b"P6\n8 8\n255\n" + raster[:100])
+    out = subprocess.run([CLI, str(short), str(tmp_path / "o.jpg")], capture_output=True, text=True)
+    assert out.returncode == 1 and "Error reading the file" in out.stdout

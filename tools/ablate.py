@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Development helper (GPU box): time the 4K encode with debug ablation flags."""
+"""Development helper (GPU box): per-stage device times of the 4K encode (HIP events);
+with a `make STAMPS=1` build and MI355_JPEG_DUMP_STAMPS=1 also the in-kernel phase shares."""
 import importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
