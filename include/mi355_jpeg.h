@@ -46,6 +46,11 @@ enum mi355_jpeg_status {
 /* flags */
 #define MI355_F_CDS 1u       /* run the 2x2 chroma averaging (performCDS, utils.cpp:113-141).
                                 Set = reference behaviour; clear = "4:4:4 (no subsample)" build convention */
+#define MI355_F_STANDARD 2u  /* SURVEY §8 f1 -- NOT a behaviour of the reference: a decodable baseline JPEG.
+                                True 8x8 DCT-II (as an exact fixed-point map, 2^-39), round-to-nearest colour
+                                conversion, 4:4:4 (MI355_F_CDS is ignored), Annex K code tables proper (without
+                                the seven 17-bit entries of huffman.hpp:92-98), EOB omitted after a non-zero
+                                coefficient 63.  Files from mi355_jpeg_encode_jfif decode in libjpeg/PIL. */
 #define MI355_F_DEFAULT MI355_F_CDS
 
 /* One Huffman table in the form the kernels consume: index (run<<4)|size,
@@ -145,7 +150,8 @@ int mi355_jpeg_probe_samples(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W
  * (zigzag_arr[chan*N + block][64], utils.cpp:482-558); out: 3*N*64 int16. */
 int mi355_jpeg_probe_coefficients(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, uint32_t H,
                                   uint32_t flags, int16_t *out);
-/* Bits each unit contributes, scan order 3*block+chan; out: 3*N uint32. */
+/* Bits each unit contributes, scan order 3*block+chan; out: 3*N uint32.  Strict mode only
+ * (MI355_E_ARG with MI355_F_STANDARD). */
 int mi355_jpeg_probe_unit_bits(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, uint32_t H,
                                uint32_t flags, uint32_t *out);
 /* Entropy-code caller-supplied coefficients (reference row order, int16) --

@@ -27,6 +27,7 @@ struct ScreenParams {
     const double* qconst;   // [2 channel types][64 zig-zag positions][4] = {s1, thr1, s2, thr2}
     const float* qconst_f;  // [2][16 groups of 4 positions][8] = {2^-20/Q x4, first-look threshold x4}
     const double* qd;       // [2][64] quantiser divisors as doubles, natural order
+    const uint32_t* qnat_zz; // [2][64] quantiser divisors as integers, ZIG-ZAG order (standard mode's exact decision)
     const uint32_t* lut;    // [4][256] Huffman LUTs (code << 5 | len)
     const uint32_t* lut2;   // [2 channel types][16 runs][64 values+32] whole AC symbols, left-aligned | length
     uint2* meta;            // [frame][tile][chan][64] {arena word offset, aclen << 16 | (uint16)dc}

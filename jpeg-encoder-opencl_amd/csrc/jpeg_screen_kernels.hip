@@ -47,28 +47,42 @@ constexpr uint32_t kSlotWordsFull = 54;  // worst case 63*(17+10)+4 = 1705 bits
 // quotient is exact for all 2^24 inputs.  Both statements are checked
 // exhaustively (tests: exhaustive colour conversion on the GPU path).
 // ----------------------------------------------------------------------------
+// STD = standard mode (not a behaviour of the reference): round to nearest
+// instead of truncating, clamp to 255; pure integer arithmetic.
+template <bool STD>
 __device__ __forceinline__ uint32_t csc_int(int chan, uint32_t r, uint32_t g, uint32_t b) {
     if (chan == 0) {
         uint32_t s = 299u * r + 587u * g + 114u * b;  // <= 255000
+        if constexpr (STD) return (s + 500u) / 1000u;
         uint32_t y = s / 1000u;
         if (s - y * 1000u == 0u) y = csc1(r, g, b, 0.299, 0.587, 0.114, 0.0);
         return y;
     } else if (chan == 1) {
         uint32_t s = 128000000u + 500000u * b - 168736u * r - 331264u * g;
+        if constexpr (STD) {
+            uint32_t v = (s + 500000u) / 1000000u;
+            return v > 255u ? 255u : v;
+        }
         return s / 1000000u;
     } else {
         uint32_t s = 128000000u + 500000u * r - 418688u * g - 81312u * b;
+        if constexpr (STD) {
+            uint32_t v = (s + 500000u) / 1000000u;
+            return v > 255u ? 255u : v;
+        }
         return s / 1000000u;
     }
 }
 
+template <bool STD>
 __device__ __forceinline__ uint32_t csc_int_at(const uint8_t* __restrict__ f, uint32_t W, uint32_t x,
                                                uint32_t y, int chan) {
     const uint8_t* p = f + ((size_t)y * W + x) * 3;
-    return csc_int(chan, p[0], p[1], p[2]);
+    return csc_int<STD>(chan, p[0], p[1], p[2]);
 }
 
 // padded pixel (px,py) of channel chan, generic path (see sample_generic)
+template <bool STD>
 __device__ __forceinline__ uint32_t sample_generic_int(const uint8_t* __restrict__ f, const Geom& g,
                                                        int chan, bool avg, uint32_t px, uint32_t py) {
     uint32_t mx = px < g.W ? px : 2 * g.W - 1 - px;
@@ -76,12 +90,12 @@ __device__ __forceinline__ uint32_t sample_generic_int(const uint8_t* __restrict
     if (avg) {
         uint32_t qx = mx & ~1u, qy = my & ~1u;
         if (qx + 1 < g.W && qy + 1 < g.H) {
-            uint32_t s = csc_int_at(f, g.W, qx, qy, chan) + csc_int_at(f, g.W, qx + 1, qy, chan) +
-                         csc_int_at(f, g.W, qx, qy + 1, chan) + csc_int_at(f, g.W, qx + 1, qy + 1, chan);
+            uint32_t s = csc_int_at<STD>(f, g.W, qx, qy, chan) + csc_int_at<STD>(f, g.W, qx + 1, qy, chan) +
+                         csc_int_at<STD>(f, g.W, qx, qy + 1, chan) + csc_int_at<STD>(f, g.W, qx + 1, qy + 1, chan);
             return s >> 2;
         }
     }
-    return csc_int_at(f, g.W, mx, my, chan);
+    return csc_int_at<STD>(f, g.W, mx, my, chan);
 }
 
 // Raw RGB of rows 2*gq, 2*gq+1 of block (bx,by): 2 x 24 bytes as six 8-byte loads (fast
@@ -103,7 +117,7 @@ __device__ __forceinline__ void load_raw_rowpair(const uint8_t* __restrict__ f, 
 
 // 16 samples of channel CHAN from the raw row pair, packed 4 per dword in sample order
 // (y*8+x), as unsigned bytes; chroma averaging over the 2x2 quads of the row pair.
-template <int CHAN>
+template <int CHAN, bool STD>
 __device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool avg, uint32_t (&pk)[4]) {
     uint32_t val[2][8];
 #pragma unroll
@@ -116,7 +130,7 @@ __device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool av
                 int byte = 3 * x + k;
                 c[k] = (w[r * 6 + (byte >> 2)] >> (8 * (byte & 3))) & 255u;
             }
-            val[r][x] = csc_int(CHAN, c[0], c[1], c[2]);
+            val[r][x] = csc_int<STD>(CHAN, c[0], c[1], c[2]);
         }
     if (avg) {
 #pragma unroll
@@ -134,7 +148,7 @@ __device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool av
 }
 
 // Edge / unaligned tiles: one sample at a time with mirroring.
-template <int CHAN>
+template <int CHAN, bool STD>
 __device__ __forceinline__ void generic_rowpair(const uint8_t* __restrict__ f, const Geom& g, bool avg,
                                                 uint32_t bx, uint32_t by, uint32_t gq, uint32_t (&pk)[4]) {
 #pragma unroll
@@ -143,7 +157,7 @@ __device__ __forceinline__ void generic_rowpair(const uint8_t* __restrict__ f, c
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
             int s = i * 4 + j;  // 0..15 within the row pair
-            uint32_t smp = sample_generic_int(f, g, CHAN, avg, bx * 8 + (s & 7), by * 8 + gq * 2 + (s >> 3));
+            uint32_t smp = sample_generic_int<STD>(f, g, CHAN, avg, bx * 8 + (s & 7), by * 8 + gq * 2 + (s >> 3));
             v |= smp << (8 * j);
         }
         pk[i] = v;
@@ -397,7 +411,7 @@ struct WalkB {  // stage B result: symbol entry read in flight
 // selects the all-zero column of the symbol table, i.e. a no-op put -- no validity bookkeeping.
 // maxcnt: wave-uniform upper bound of the lanes' non-zero counts (wave_max of popcount(mask),
 // formed by the caller with all lanes active: DPP reductions need the full wave).
-template <typename Store>
+template <bool STD, typename Store>
 __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, const uint32_t* __restrict__ lut2,
                                               const uint32_t* __restrict__ act, Packer32<Store>& pk,
                                               const uint32_t maxcnt) {
@@ -452,7 +466,8 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
         a2 = a3;
         b1 = b2;
     }
-    pk.put(lut2[kLut2Eob]);  // ALWAYS (quirk Q8)
+    // the reference appends EOB ALWAYS (quirk Q8); a standard encoder omits it after coefficient 63
+    if (!(STD && (mask >> 63))) pk.put(lut2[kLut2Eob]);
     pk.finish();
     return ok;
 }
@@ -481,7 +496,7 @@ constexpr uint32_t kEncWaves = 4;
 #define STAMP(i) do { } while (0)
 #endif
 
-template <bool PROBE>
+template <bool PROBE, bool STD>
 __global__ void __launch_bounds__(256, 2)
     k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
     __shared__ uint32_t s_tbuf_all[kEncWaves][64 * 33];            // zig-zag rows, int16 pairs, stride 33 dwords
@@ -557,7 +572,7 @@ __global__ void __launch_bounds__(256, 2)
         }
         const uint32_t ct = chan ? 1u : 0u;
         const uint8_t* f = rgb + (size_t)frame * g.frame_stride;
-        const bool avg = (chan != 0) && (g.flags & 1u);
+        const bool avg = !STD && (chan != 0) && (g.flags & 1u);  // standard mode is 4:4:4
         const size_t us_base = (((size_t)frame * g.tiles + tile) * 3 + chan) * 64;
 
         // block coordinates of this lane's four blocks (16j + n), and whether the whole tile
@@ -622,13 +637,13 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
                 for (int i = 0; i < 12; ++i) cur[i] = raw[i];
                 if (j < 3) load_raw_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, raw);
-                if (chan == 0) convert_rowpair<0>(cur, false, pk);
-                else if (chan == 1) convert_rowpair<1>(cur, avg, pk);
-                else convert_rowpair<2>(cur, avg, pk);
+                if (chan == 0) convert_rowpair<0, STD>(cur, false, pk);
+                else if (chan == 1) convert_rowpair<1, STD>(cur, avg, pk);
+                else convert_rowpair<2, STD>(cur, avg, pk);
             } else {
-                if (chan == 0) generic_rowpair<0>(f, g, false, bx, by, gq, pk);
-                else if (chan == 1) generic_rowpair<1>(f, g, avg, bx, by, gq, pk);
-                else generic_rowpair<2>(f, g, avg, bx, by, gq, pk);
+                if (chan == 0) generic_rowpair<0, STD>(f, g, false, bx, by, gq, pk);
+                else if (chan == 1) generic_rowpair<1, STD>(f, g, avg, bx, by, gq, pk);
+                else generic_rowpair<2, STD>(f, g, avg, bx, by, gq, pk);
             }
             if constexpr (PROBE) {
                 if (sp.samples && tile * 64 + 16 * j + n < g.N) {
@@ -650,9 +665,18 @@ __global__ void __launch_bounds__(256, 2)
             const v4i B = v4i{(int)(pk[0] ^ 0x80808080u), (int)(pk[1] ^ 0x80808080u),
                               (int)(pk[2] ^ 0x80808080u), (int)(pk[3] ^ 0x80808080u)};
 
-            // exact coefficient 0: c0 = fl(sum * SCALE_00), q0 = round(c0 / Q0)   (utils.cpp:336,459)
-            const double c0 = (double)((int)ssum - 8192) * kScale00;
-            const int q0 = (int)__builtin_round(c0 / sp.qd[ct * 64]);
+            // exact coefficient 0.  Strict: c0 = fl(sum * SCALE_00), q0 = round(c0 / Q0) (utils.cpp:336,459).
+            // Standard: row 0 of the true DCT is exactly 1/8, q0 = round-half-away(sum / (8 Q0)) in integers.
+            int q0;
+            if constexpr (STD) {
+                const int sl = (int)ssum - 8192;
+                const uint32_t Q0 = (uint32_t)sp.qd[ct * 64], a0 = (uint32_t)(sl < 0 ? -sl : sl);
+                const int n0 = (int)((a0 + 4u * Q0) / (8u * Q0));
+                q0 = sl < 0 ? -n0 : n0;
+            } else {
+                const double c0 = (double)((int)ssum - 8192) * kScale00;
+                q0 = (int)__builtin_round(c0 / sp.qd[ct * 64]);
+            }
 
             bool amb = false;
             uint32_t nzlo = 0, nzhi = 0;  // this lane's part of the unit's non-zero mask
@@ -709,12 +733,21 @@ __global__ void __launch_bounds__(256, 2)
                             const double* qc = &s_qc[ct][16 * mt + 4 * gq + r][0];
                             const double y1 = (double)hi[r] * 65536.0 + (double)mid[r];  // exact
                             const double y2 = y1 * 256.0 + (double)acc0[r];              // exact
-                            const double z = y2 * qc[2];
-                            const double t = __builtin_fabs(z) + 0.5;
-                            const double fr = t - __builtin_floor(t);
-                            const int nn = (int)t;
-                            qb[r] = (uint32_t)(z < 0.0 ? -nn : nn);
-                            amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
+                            if constexpr (STD) {
+                                // standard mode is DEFINED by the fixed-point map: decide exactly in integers
+                                const long long Y = (long long)y2;
+                                const unsigned long long Dq = (unsigned long long)sp.qnat_zz[ct * 64 + 16 * mt + 4 * gq + r] << 39;
+                                const unsigned long long a = (unsigned long long)(Y < 0 ? -Y : Y);
+                                const unsigned long long nn = (2 * a + Dq) / (2 * Dq);
+                                qb[r] = (uint32_t)(Y < 0 ? -(long long)nn : (long long)nn);
+                            } else {
+                                const double z = y2 * qc[2];
+                                const double t = __builtin_fabs(z) + 0.5;
+                                const double fr = t - __builtin_floor(t);
+                                const int nn = (int)t;
+                                qb[r] = (uint32_t)(z < 0.0 ? -nn : nn);
+                                amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
+                            }
                         }
                     }
                 }
@@ -750,7 +783,7 @@ __global__ void __launch_bounds__(256, 2)
 
         Packer32<StoreLds> pkr(StoreLds{&s_slot[lane]});
         const uint32_t maxcnt = wave_max((uint32_t)__popcll(mask));
-        bool ok = walk_nonzeros(row16, mask, s_lut2[ct], s_act[ct], pkr, maxcnt);
+        bool ok = walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pkr, maxcnt);
         const uint32_t aclen = pkr.bits();
         uint32_t nw = pkr.words();
         STAMP(2);
@@ -769,18 +802,26 @@ __global__ void __launch_bounds__(256, 2)
             if (tile > 0) {
                 uint32_t sm;
                 if (pred_fast) {
-                    sm = chan == 0 ? csc_int(0, pr, pg, pbl) : (chan == 1 ? csc_int(1, pr, pg, pbl) : csc_int(2, pr, pg, pbl));
+                    sm = chan == 0 ? csc_int<STD>(0, pr, pg, pbl)
+                                   : (chan == 1 ? csc_int<STD>(1, pr, pg, pbl) : csc_int<STD>(2, pr, pg, pbl));
                     if (avg) {  // 2x2 mean of the quad (lane = y*8+x: partners x^1, y^1)
                         uint32_t s4 = sm + (uint32_t)__shfl_xor((int)sm, 1);
                         s4 += (uint32_t)__shfl_xor((int)s4, 8);
                         sm = s4 >> 2;
                     }
                 } else {
-                    sm = sample_generic_int(f, g, (int)chan, avg, pbx * 8 + (lane & 7), pby * 8 + (lane >> 3));
+                    sm = sample_generic_int<STD>(f, g, (int)chan, avg, pbx * 8 + (lane & 7), pby * 8 + (lane >> 3));
                 }
                 sm = wave_sum(sm);
-                const double pc0 = (double)((int)sm - 8192) * kScale00;
-                pred0 = (int)__builtin_round(pc0 / sp.qd[ct * 64]);
+                if constexpr (STD) {
+                    const int sl = (int)sm - 8192;
+                    const uint32_t Q0 = (uint32_t)sp.qd[ct * 64], a0 = (uint32_t)(sl < 0 ? -sl : sl);
+                    const int n0 = (int)((a0 + 4u * Q0) / (8u * Q0));
+                    pred0 = sl < 0 ? -n0 : n0;
+                } else {
+                    const double pc0 = (double)((int)sm - 8192) * kScale00;
+                    pred0 = (int)__builtin_round(pc0 / sp.qd[ct * 64]);
+                }
             }
             int pred = __shfl_up(dc, 1);
             if (lane == 0) pred = pred0;
@@ -812,7 +853,7 @@ __global__ void __launch_bounds__(256, 2)
             if (__any(oversize && nw)) {  // rare: string longer than the LDS slot: walk again, straight to memory
                 if (oversize && nw) {
                     Packer32<StoreGlobal> pg(StoreGlobal{sp.arena + off});
-                    (void)walk_nonzeros(row16, mask, s_lut2[ct], s_act[ct], pg, maxcnt);
+                    (void)walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pg, maxcnt);
                 }
             }
         }
@@ -1082,10 +1123,15 @@ uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves) {
 hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,
                                 bool probe, uint32_t grid_waves, hipStream_t s) {
     uint32_t grid = screen_grid(g, n_frames, grid_waves) / kEncWaves;
-    if (probe)
-        hipLaunchKernelGGL((k_screen_encode<true>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
+    const bool stdm = (g.flags & 2u) != 0;  // MI355_F_STANDARD
+    if (probe && stdm)
+        hipLaunchKernelGGL((k_screen_encode<true, true>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
+    else if (probe)
+        hipLaunchKernelGGL((k_screen_encode<true, false>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
+    else if (stdm)
+        hipLaunchKernelGGL((k_screen_encode<false, true>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
     else
-        hipLaunchKernelGGL((k_screen_encode<false>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
+        hipLaunchKernelGGL((k_screen_encode<false, false>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
     return hipGetLastError();
 }
 hipError_t launch_fixup(const Geom& g, const uint8_t* rgb, const ScreenParams& sp, bool probe,

@@ -79,7 +79,9 @@ void canonical(const uint8_t bits[16], const uint8_t* val, mi355_huff_table* t) 
 // The reference's four code tables.  DC tables have 12 entries (sizes 0..11), AC
 // tables 16 runs x 11 sizes (0..10); everything else has no code.  huffman.hpp:92-98
 // spells AC-luma run 3 / sizes 4..10 with one extra leading '1' (17 bits): kept.
-void reference_huffman(int table, mi355_huff_table* t) {
+// typos: true = the reference's tables (huffman.hpp incl. the seven 17-bit entries);
+// false = the Annex K codes proper (standard mode).
+void reference_huffman(int table, mi355_huff_table* t, bool typos = true) {
     switch (table) {
         case 0: canonical(kBitsDcL, kValDc, t); break;
         case 1: canonical(kBitsDcC, kValDc, t); break;
@@ -91,7 +93,7 @@ void reference_huffman(int table, mi355_huff_table* t) {
         bool has = table < 2 ? (run == 0 && size <= 11) : (size <= 10 && (size > 0 || run == 0 || run == 15));
         if (!has) t->len[rs] = 0, t->code[rs] = 0;
     }
-    if (table == 2)
+    if (table == 2 && typos)
         for (int s = 4; s <= 10; ++s) {
             int rs = (3 << 4) | s;
             t->code[rs] |= 1u << t->len[rs];
@@ -111,9 +113,11 @@ struct mi355_jpeg_ctx {
     int device = 0;
     uint32_t qlum[64], qchrom[64];
     mi355_huff_table huff[4];
+    mi355_huff_table huff_std[4];  // standard mode (MI355_F_STANDARD): Annex K proper unless the caller set a table
     // device-resident tables
     double* d_q = nullptr;       // [2][64] doubles, natural order
-    uint32_t* d_lut = nullptr;   // [4][256] code<<5|len
+    uint32_t* d_qzz = nullptr;   // [2][64] integers, zig-zag order (standard mode)
+    uint32_t* d_lut = nullptr;   // [2 modes][4][256] code<<5|len (second set: standard mode)
     uint32_t* d_status = nullptr;
     // workspace (grown on demand, never shrunk)
     uint32_t* d_coefs = nullptr;
@@ -132,10 +136,10 @@ struct mi355_jpeg_ctx {
     uint64_t* d_bits = nullptr;
     size_t bits_cap = 0;
     // screened (integer-MFMA) pipeline
-    uint4* d_afrag = nullptr;       // MFMA A fragments of the fixed-point map (static)
+    uint4* d_afrag = nullptr;       // MFMA A fragments of the fixed-point maps (static): [strict, standard]
     double* d_qconst = nullptr;     // [2][64][4] accept thresholds for the current tables
     float* d_qconst_f = nullptr;    // [2][16][8] fp32 first-look scale factors and thresholds
-    uint32_t* d_lut2 = nullptr;     // [2][16][64] whole AC symbols for |value| <= 31
+    uint32_t* d_lut2 = nullptr;     // [2 modes][2][16][64] whole AC symbols for |value| <= 31
     uint32_t* d_counters = nullptr; // [0] arena words, [1] fix-up list length
     uint2* d_meta = nullptr;
     size_t meta_cap = 0;
@@ -185,10 +189,15 @@ int upload_tables(mi355_jpeg_ctx* c) {
         q[i] = (double)c->qlum[i];
         q[64 + i] = (double)c->qchrom[i];
     }
-    uint32_t lut[4 * 256];
-    for (int t = 0; t < 4; ++t)
-        for (int i = 0; i < 256; ++i)
-            lut[t * 256 + i] = c->huff[t].len[i] ? ((c->huff[t].code[i] << 5) | c->huff[t].len[i]) : 0u;
+    static const uint8_t zz[64] = MI355_ZIGZAG_TABLE;
+    uint32_t lut[2 * 4 * 256], qzz[128];
+    for (int m = 0; m < 2; ++m)
+        for (int t = 0; t < 4; ++t) {
+            const mi355_huff_table& h = m ? c->huff_std[t] : c->huff[t];
+            for (int i = 0; i < 256; ++i) lut[(m * 4 + t) * 256 + i] = h.len[i] ? ((h.code[i] << 5) | h.len[i]) : 0u;
+        }
+    for (int R = 0; R < 64; ++R) qzz[R] = c->qlum[zz[R]], qzz[64 + R] = c->qchrom[zz[R]];
+    HIP_TRY(hipMemcpy(c->d_qzz, qzz, sizeof qzz, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_q, q, sizeof q, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
     // Accept thresholds of the screened transform (jpeg_screen_kernels.hip), per channel type
@@ -196,7 +205,8 @@ int upload_tables(mi355_jpeg_ctx* c) {
     //   first look  (top four digits):  |c/Q - z1| <= (2^-19 + eps_R + fixerr)/Q + fp slop
     //   second look (all five digits):  |c/Q - z2| <= (eps_R + fixerr)/Q + fp slop
     // fp slop: z = y*s (relative 2^-52 of |z| < 2^12) and |z|+0.5 (2^-41): 2^-38 covers both.
-    static const uint8_t zz[64] = MI355_ZIGZAG_TABLE;
+    // Standard mode shares the first-look constants: its map is the definition (delta = 0), so the
+    // strict margins are merely wider than needed; its second look decides exactly in integers.
     double qc[2][64][4];
     for (int ct = 0; ct < 2; ++ct)
         for (int R = 0; R < 64; ++R) {
@@ -234,37 +244,41 @@ int upload_tables(mi355_jpeg_ctx* c) {
     // the Huffman code of (r, size(v)) followed by v's value bits, left-aligned in 32 bits, with
     // the total length in bits 4..0; 0 = the reference has no code.  The value-0 column stays 0 (a
     // no-op for lanes that ran out of non-zeros); ZRL and EOB live in the unused value -32 column.
-    std::vector<uint32_t> lut2(2 * 1024, 0u);
-    for (int ct = 0; ct < 2; ++ct) {
-        const mi355_huff_table& t = c->huff[2 + ct];
-        auto entry = [&](uint32_t bits, int len) -> uint32_t { return len ? ((bits << (32 - len)) | (uint32_t)len) : 0u; };
-        for (int r = 0; r < 16; ++r)
-            for (int v = -31; v <= 31; ++v) {
-                if (v == 0) continue;
-                int a = v < 0 ? -v : v, size = 0;
-                while (a) ++size, a >>= 1;
-                int rs = (r << 4) | size;
-                if (!t.len[rs]) continue;
-                uint32_t vb = (uint32_t)(v < 0 ? v + (1 << size) - 1 : v);
-                lut2[ct * 1024 + r * 64 + v + 32] = entry((t.code[rs] << size) | vb, t.len[rs] + size);
-            }
-        lut2[ct * 1024 + 15 * 64 + 0] = entry(t.code[0xF0], t.len[0xF0]);  // ZRL in the unused value -32 column
-        lut2[ct * 1024 + 0] = entry(t.code[0x00], t.len[0x00]);            // EOB likewise; column 32 (value 0) stays 0
-    }
+    std::vector<uint32_t> lut2(2 * 2 * 1024, 0u);
+    for (int m = 0; m < 2; ++m)
+        for (int ct = 0; ct < 2; ++ct) {
+            const mi355_huff_table& t = m ? c->huff_std[2 + ct] : c->huff[2 + ct];
+            uint32_t* L = &lut2[(size_t)(m * 2 + ct) * 1024];
+            auto entry = [&](uint32_t bits, int len) -> uint32_t { return len ? ((bits << (32 - len)) | (uint32_t)len) : 0u; };
+            for (int r = 0; r < 16; ++r)
+                for (int v = -31; v <= 31; ++v) {
+                    if (v == 0) continue;
+                    int a = v < 0 ? -v : v, size = 0;
+                    while (a) ++size, a >>= 1;
+                    int rs = (r << 4) | size;
+                    if (!t.len[rs]) continue;
+                    uint32_t vb = (uint32_t)(v < 0 ? v + (1 << size) - 1 : v);
+                    L[r * 64 + v + 32] = entry((t.code[rs] << size) | vb, t.len[rs] + size);
+                }
+            L[15 * 64 + 0] = entry(t.code[0xF0], t.len[0xF0]);  // ZRL in the unused value -32 column
+            L[0] = entry(t.code[0x00], t.len[0x00]);            // EOB likewise; column 32 (value 0) stays 0
+        }
     HIP_TRY(hipMemcpy(c->d_lut2, lut2.data(), lut2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return MI355_OK;
 }
 
 // MFMA A fragments of the fixed-point map: fragment (mt, digit), lane l = (m = l & 15, g = l >> 4)
 // holds row 16*mt + m (a zig-zag position), input samples 16*g .. 16*g+15.
+constexpr size_t kAfragBytes = (size_t)4 * kScreenLimbs * 64 * 16;  // one map
 int upload_afrag(mi355_jpeg_ctx* c) {
-    std::vector<int8_t> h((size_t)4 * kScreenLimbs * 64 * 16);
-    for (int mt = 0; mt < 4; ++mt)
-        for (int l = 0; l < kScreenLimbs; ++l)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int i = 0; i < 16; ++i)
-                    h[(((size_t)mt * kScreenLimbs + l) * 64 + lane) * 16 + i] =
-                        kScreenLimb[l][16 * mt + (lane & 15)][16 * (lane >> 4) + i];
+    std::vector<int8_t> h(2 * kAfragBytes);
+    for (int m = 0; m < 2; ++m)  // 0: the reference's chain as a linear map; 1: the true DCT-II (standard mode)
+        for (int mt = 0; mt < 4; ++mt)
+            for (int l = 0; l < kScreenLimbs; ++l)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 16; ++i)
+                        h[m * kAfragBytes + (((size_t)mt * kScreenLimbs + l) * 64 + lane) * 16 + i] =
+                            (m ? kStdLimb : kScreenLimb)[l][16 * mt + (lane & 15)][16 * (lane >> 4) + i];
     HIP_TRY(hipMemcpy(c->d_afrag, h.data(), h.size(), hipMemcpyHostToDevice));
     return MI355_OK;
 }
@@ -330,12 +344,14 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     const size_t arena_words = plan.total_words;
     sp.region_words = plan.region_words;
     sp.overflow_base = plan.grid * plan.region_words;
-    sp.afrag = c->d_afrag;
+    const bool stdm = (g.flags & MI355_F_STANDARD) != 0;
+    sp.afrag = c->d_afrag + (stdm ? kAfragBytes / sizeof(uint4) : 0);
     sp.qconst = c->d_qconst;
     sp.qconst_f = c->d_qconst_f;
     sp.qd = c->d_q;
-    sp.lut = c->d_lut;
-    sp.lut2 = c->d_lut2;
+    sp.qnat_zz = c->d_qzz;
+    sp.lut = c->d_lut + (stdm ? 1024 : 0);
+    sp.lut2 = c->d_lut2 + (stdm ? 2048 : 0);
     sp.meta = c->d_meta;
     sp.arena = c->d_arena;
     sp.arena_words = (uint32_t)(arena_words > 0xFFFFFFFFull ? 0xFFFFFFFFull : arena_words);
@@ -433,7 +449,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
                              c->d_status, c->d_counters, true, s));
     record(c, 3, s);
-    HIP_TRY(launch_merge(g, n_frames, c->d_meta, c->d_arena, c->d_lut, c->d_tile_off, d_out,
+    HIP_TRY(launch_merge(g, n_frames, c->d_meta, c->d_arena, sp.lut, c->d_tile_off, d_out,
                          out_stride, c->d_status, c->emit_lds_words, s));
     record(c, 4, s);
     return MI355_OK;
@@ -500,7 +516,7 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     if (!c) return MI355_E_ALLOC;
     c->device = device_id;
     for (int i = 0; i < 64; ++i) c->qlum[i] = kQ50Lum[i], c->qchrom[i] = kQ50Chr[i];
-    for (int t = 0; t < 4; ++t) reference_huffman(t, &c->huff[t]);
+    for (int t = 0; t < 4; ++t) reference_huffman(t, &c->huff[t]), reference_huffman(t, &c->huff_std[t], false);
     const char* m = getenv("MI355_JPEG_TRANSFORM_MODE");
     if (m) c->transform_mode = atoi(m);
     const char* l = getenv("MI355_JPEG_EMIT_LDS_WORDS");
@@ -511,12 +527,13 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     if (sw && atoi(sw) > 0) c->screen_waves = (uint32_t)atoi(sw);
     int e = MI355_OK;
     if (hipMalloc((void**)&c->d_q, 128 * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&c->d_lut, 1024 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->d_qzz, 128 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->d_lut, 2048 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_status, sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_afrag, (size_t)4 * kScreenLimbs * 64 * 16) != hipSuccess ||
+        hipMalloc((void**)&c->d_afrag, 2 * kAfragBytes) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst_f, 256 * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&c->d_lut2, 2048 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->d_lut2, 4096 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_counters, 2 * sizeof(uint32_t)) != hipSuccess)
         e = MI355_E_ALLOC;
     if (!e) e = hip_err(hipMemset(c->d_status, 0, sizeof(uint32_t)));
@@ -537,7 +554,7 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
                     c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
                     c->d_counters, c->d_meta,     c->d_arena,  c->d_fixlist, c->d_lut2,     c->d_qconst_f,
-                    c->d_stuff_counts, c->d_stuff_offs};
+                    c->d_stuff_counts, c->d_stuff_offs, c->d_qzz};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& es : c->ev_pool)
@@ -578,8 +595,10 @@ int mi355_jpeg_set_huffman(mi355_jpeg_ctx* c, int table, const mi355_huff_table*
             if (nt.len[i] && (nt.code[i] >> nt.len[i])) return MI355_E_TABLE;
         }
         if (table >= 2 && (!nt.len[0x00] || !nt.len[0xF0])) return MI355_E_TABLE;  // EOB and ZRL are always needed
+        c->huff_std[table] = nt;
     } else {
         reference_huffman(table, &nt);
+        reference_huffman(table, &c->huff_std[table], false);
     }
     c->huff[table] = nt;
     HIP_TRY(hipSetDevice(c->device));
@@ -626,6 +645,7 @@ int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t
     int e = make_geom(W, H, flags, d_rgb, &g);
     if (e) return e;
     if (n_frames > 65535u) return MI355_E_ARG;
+    if ((flags & MI355_F_STANDARD) && c->transform_mode != 2) return MI355_E_ARG;  // the exact pipeline is strict only
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
     if (c->transform_mode == 2) {
@@ -704,6 +724,7 @@ int mi355_jpeg_probe_samples(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, 
     if ((e = ensure(c->d_in, c->in_cap, (size_t)g.frame_stride))) return e;
     if ((e = ensure(c->d_out, c->out_cap, ob))) return e;
     HIP_TRY(hipMemcpy(c->d_in, rgb, g.frame_stride, hipMemcpyHostToDevice));
+    if ((flags & MI355_F_STANDARD) && c->transform_mode != 2) return MI355_E_ARG;
     if (c->transform_mode == 2) {
         // the screened pipeline has its own (integer-exact) sample stage: probe that one
         if ((e = ensure_workspace(c, g, 1))) return e;
@@ -719,6 +740,7 @@ static int transform_to_workspace(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_
                                   uint32_t flags, Geom* g) {
     int e = make_geom(W, H, flags, nullptr, g);
     if (e) return e;
+    if ((flags & MI355_F_STANDARD) && c->transform_mode != 2) return MI355_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     if ((e = ensure(c->d_in, c->in_cap, (size_t)g->frame_stride))) return e;
     if ((e = ensure_workspace(c, *g, 1))) return e;
@@ -744,6 +766,7 @@ int mi355_jpeg_probe_coefficients(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_
 int mi355_jpeg_probe_unit_bits(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
                                uint32_t* out) {
     if (!c || !rgb || !out) return MI355_E_ARG;
+    if (flags & MI355_F_STANDARD) return MI355_E_ARG;  // the per-unit size kernel codes the reference's rules only
     Geom g;
     int e = transform_to_workspace(c, rgb, W, H, flags, &g);
     if (e) return e;
@@ -854,10 +877,11 @@ int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, ui
     w.b(1), w.b(0x11), w.b(0);
     w.b(2), w.b(0x11), w.b(1);
     w.b(3), w.b(0x11), w.b(1);
-    dht_segment(w, 0x00, c->huff[0]);
-    dht_segment(w, 0x10, c->huff[2]);
-    dht_segment(w, 0x01, c->huff[1]);
-    dht_segment(w, 0x11, c->huff[3]);
+    const mi355_huff_table* ht = (flags & MI355_F_STANDARD) ? c->huff_std : c->huff;
+    dht_segment(w, 0x00, ht[0]);
+    dht_segment(w, 0x10, ht[2]);
+    dht_segment(w, 0x01, ht[1]);
+    dht_segment(w, 0x11, ht[3]);
     w.w(0xFFDA), w.w(12), w.b(3);
     w.b(1), w.b(0x00), w.b(2), w.b(0x11), w.b(3), w.b(0x11);
     w.b(0), w.b(63), w.b(0);

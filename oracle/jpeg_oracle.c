@@ -127,7 +127,8 @@ typedef struct {
     uint8_t len[256]; /* 0 = no code */
 } huff_tab;
 
-static huff_tab HT[4]; /* DC luma, DC chroma, AC luma, AC chroma; index = run<<4 | size */
+static huff_tab HT[4];  /* DC luma, DC chroma, AC luma, AC chroma; index = run<<4 | size */
+static huff_tab HTS[4]; /* the same without the reference's 17-bit typos (standard mode) */
 static int HT_ready;
 
 static void canon(const uint8_t bits[16], const uint8_t *val, huff_tab *t) {
@@ -150,6 +151,7 @@ static void build_tables(void) {
     canon(BITS_DC_C, VAL_DC, &HT[1]);
     canon(BITS_AC_L, VAL_AC_L, &HT[2]);
     canon(BITS_AC_C, VAL_AC_C, &HT[3]);
+    memcpy(HTS, HT, sizeof HT);
     /* quirk Q11 (huffman.hpp:92-98): the AC-luma codes for run 3, sizes 4..10
      * carry one extra leading '1' and are 17 bits long. */
     for (int s = 4; s <= 10; ++s) {
@@ -466,6 +468,123 @@ void orc_result_free(orc_result *r) {
     free(r->bits), free(r->zigzag), free(r->unit_bits);
     free(r->csc), free(r->cds), free(r->padded), free(r->dct);
     memset(r, 0, sizeof *r);
+}
+
+/* ------------------------------------------------------------ standard mode */
+
+static int std_code(int table, int run, int size, uint32_t *code) {
+    build_tables();
+    if (table < 2 ? (run != 0 || size > 11) : (run > 15 || size > 10)) return -1;
+    int rs = (run << 4) | size;
+    if (!HTS[table].len[rs]) return -1;
+    *code = HTS[table].code[rs];
+    return HTS[table].len[rs];
+}
+
+static int std_symbol(struct orc_bitsink *sink, int table, int run, int32_t v, int *nbits) {
+    int size = bit_size(v);
+    uint32_t code;
+    int len = std_code(table, run, size, &code);
+    if (len < 0) return ORC_E_CATEGORY;
+    *nbits += len + size;
+    if (sink) {
+        int e = sink_put(sink, code, len);
+        if (!e && size) e = sink_put(sink, value_bits(v, size), size);
+        if (e) return e;
+    }
+    return 0;
+}
+
+static int std_unit(const int32_t zz[64], int32_t dc_diff, int chroma, struct orc_bitsink *sink) {
+    int nbits = 0, e;
+    if ((e = std_symbol(sink, chroma ? 1 : 0, 0, dc_diff, &nbits))) return e;
+    int run = 0, tab = chroma ? 3 : 2;
+    for (int i = 1; i < 64; ++i) {
+        if (zz[i] == 0) {
+            ++run;
+            continue;
+        }
+        while (run >= 16) {
+            if ((e = std_symbol(sink, tab, 15, 0, &nbits))) return e;
+            run -= 16;
+        }
+        if ((e = std_symbol(sink, tab, run, zz[i], &nbits))) return e;
+        run = 0;
+    }
+    if (run > 0 && (e = std_symbol(sink, tab, 0, 0, &nbits))) return e; /* EOB only if zeros remain */
+    return nbits;
+}
+
+int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
+                   const uint32_t qchrom[64], const int64_t *dct, int keep, orc_result *out) {
+    if (!rgb || !out || !dct || W == 0 || H == 0) return ORC_E_ARG;
+    memset(out, 0, sizeof *out);
+    size_t W8, H8;
+    orc_padded_size(W, H, &W8, &H8);
+    if (W8 - W > W || H8 - H > H) return ORC_E_ARG;
+    const size_t N = W8 * H8 / 64, bw = W8 / 8;
+    out->W8 = W8, out->H8 = H8, out->n_blocks = N;
+    uint8_t *img = (uint8_t *)malloc(W * H * 3), *pad = (uint8_t *)malloc(W8 * H8 * 3);
+    int32_t *zig = (int32_t *)malloc(N * 3 * 64 * sizeof(int32_t));
+    for (size_t i = 0; i < W * H; ++i) {
+        long r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+        long y = (299 * r + 587 * g + 114 * b + 500) / 1000;
+        long cb = (128000000L + 500000 * b - 168736 * r - 331264 * g + 500000) / 1000000;
+        long cr = (128000000L + 500000 * r - 418688 * g - 81312 * b + 500000) / 1000000;
+        img[3 * i] = (uint8_t)(y > 255 ? 255 : y);
+        img[3 * i + 1] = (uint8_t)(cb > 255 ? 255 : cb);
+        img[3 * i + 2] = (uint8_t)(cr > 255 ? 255 : cr);
+    }
+    orc_pad(img, W, H, pad, W8, H8);
+    free(img);
+    uint8_t zz[64];
+    orc_zigzag_order(zz);
+    for (size_t by = 0; by < H8 / 8; ++by)
+        for (size_t bx = 0; bx < bw; ++bx)
+            for (int c = 0; c < 3; ++c) {
+                int32_t p[64];
+                for (int s = 0; s < 64; ++s)
+                    p[s] = (int32_t)pad[3 * ((by * 8 + s / 8) * W8 + bx * 8 + s % 8) + c] - 128;
+                int32_t *row = zig + ((size_t)c * N + by * bw + bx) * 64;
+                const uint32_t *q = c == 0 ? qlum : qchrom;
+                for (int R = 0; R < 64; ++R) {
+                    int64_t Y = 0;
+                    for (int s = 0; s < 64; ++s) Y += dct[R * 64 + s] * p[s];
+                    int64_t D = (int64_t)q[zz[R]] << 39, a = Y < 0 ? -Y : Y;
+                    int64_t n = (2 * a + D) / (2 * D);
+                    row[R] = (int32_t)(Y < 0 ? -n : n);
+                }
+            }
+    free(pad);
+    if (keep & ORC_KEEP_UNIT_BITS) out->unit_bits = (uint32_t *)malloc(N * 3 * sizeof(uint32_t));
+    struct orc_bitsink sink = {0, 0, 0};
+    int32_t pred[3] = {0, 0, 0};
+    int err = 0;
+    for (size_t i = 0; i < N && !err; ++i)
+        for (int c = 0; c < 3; ++c) {
+            const int32_t *r = zig + (i + N * (size_t)c) * 64;
+            int32_t diff = r[0] - pred[c];
+            pred[c] = r[0];
+            int n = std_unit(r, diff, c != 0, &sink);
+            if (n < 0) {
+                err = n;
+                break;
+            }
+            if (out->unit_bits) out->unit_bits[3 * i + c] = (uint32_t)n;
+        }
+    if (err) {
+        free(sink.buf), free(zig);
+        orc_result_free(out);
+        return err;
+    }
+    out->bits = sink.buf;
+    out->n_bits = sink.nbit;
+    out->bits_bytes = (size_t)((sink.nbit + 7) / 8);
+    if (keep & ORC_KEEP_ZIGZAG)
+        out->zigzag = zig;
+    else
+        free(zig);
+    return ORC_OK;
 }
 
 void orc_lcg_fill(uint8_t *dst, size_t nbytes, uint32_t seed) {

@@ -97,6 +97,22 @@ void orc_result_free(orc_result *r);
 int orc_entropy(const int32_t *zigzag, size_t n_blocks, uint8_t **bits, size_t *bits_bytes,
                 uint64_t *n_bits, uint32_t *unit_bits /* [3N] or NULL */);
 
+/* ---- standard mode --------------------------------------------
+ * NOT a behaviour of the reference (parity unpinned by it): a decodable baseline
+ * JPEG, 4:4:4, defined entirely in integer arithmetic so that the GPU path and
+ * this checker agree bit for bit:
+ *   samples  Y  = min(255, (299R+587G+114B+500)/1000), Cb/Cr likewise with the
+ *            1e6-scaled constants (round to nearest instead of the reference's
+ *            truncation), mirror padding as in strict mode;
+ *   DCT      q[R] = round-half-away( sum_s dct[R][s]*(smp[s]-128) / (Q*2^39) ),
+ *            dct = the true DCT-II rounded to 2^-39, rows in zig-zag order
+ *            (tests/golden/std_dct_q39.i64, tools/gen_screen_tables.py);
+ *   entropy  Annex-K tables without the reference's seven 17-bit typos, EOB
+ *            omitted when coefficient 63 is non-zero.
+ * keep: ORC_KEEP_ZIGZAG / ORC_KEEP_UNIT_BITS. */
+int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
+                   const uint32_t qchrom[64], const int64_t *dct, int keep, orc_result *out);
+
 /* Pinned synthetic input of SURVEY §8d: LCG s <- s*1664525+1013904223,
  * byte = s>>24, seed = 1+frame. */
 void orc_lcg_fill(uint8_t *dst, size_t nbytes, uint32_t seed);

@@ -56,6 +56,9 @@ def oracle():
         L.orc_entropy.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)),
                                   C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.c_void_p]
         L.orc_lcg_fill.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
+        L.orc_std_encode.restype = C.c_int
+        L.orc_std_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.POINTER(OrcResult)]
         L.orc_jfif_frame.restype = C.c_long
         L.orc_jfif_frame.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_size_t]
@@ -177,6 +180,51 @@ def oracle_encode(rgb, qlum=None, qchrom=None, cds_on=True, keep=0):
     out.padded = np.ctypeslib.as_array(res.padded, (res.H8, res.W8, 3)).copy() if res.padded else None
     out.dct = np.ctypeslib.as_array(res.dct, (res.H8, res.W8, 3)).copy() if res.dct else None
     out.stage_us = list(res.stage_us)
+    oracle().orc_result_free(C.byref(res))
+    return out
+
+
+def zigzag_order():
+    """zz[k] = natural index (v*8+u) of zig-zag position k."""
+    zz = np.zeros(64, np.uint8)
+    oracle().orc_zigzag_order(zz.ctypes.data)
+    return zz
+
+
+def oracle_entropy(zigzag):
+    """performRLE + HuffmanEncoder (the reference's rules) on int32 rows [3N][64]: (packed bits, n_bits)."""
+    z = np.ascontiguousarray(zigzag, np.int32)
+    N = z.shape[0] // 3
+    out, nb, n = C.POINTER(C.c_uint8)(), C.c_size_t(), C.c_uint64()
+    rc = oracle().orc_entropy(z.ctypes.data, N, C.byref(out), C.byref(nb), C.byref(n), None)
+    if rc != 0:
+        raise RuntimeError("orc_entropy failed: %d" % rc)
+    return np.ctypeslib.as_array(out, (nb.value,)).copy(), int(n.value)
+
+
+def std_dct_table():
+    """The fixed-point true-DCT table that DEFINES standard mode (tests/golden/std_dct_q39.i64)."""
+    return np.fromfile(os.path.join(ROOT, "tests", "golden", "std_dct_q39.i64"), "<i8").reshape(64, 64)
+
+
+def oracle_std_encode(rgb, qlum, qchrom, keep=0):
+    """Standard (decodable, 4:4:4) mode of the test oracle."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    H, W, _ = rgb.shape
+    qlum = np.ascontiguousarray(qlum, np.uint32)
+    qchrom = np.ascontiguousarray(qchrom, np.uint32)
+    dct = np.ascontiguousarray(std_dct_table(), np.int64)
+    res = OrcResult()
+    rc = oracle().orc_std_encode(rgb.ctypes.data, W, H, qlum.ctypes.data, qchrom.ctypes.data, dct.ctypes.data,
+                                 keep, C.byref(res))
+    if rc != 0:
+        raise RuntimeError("orc_std_encode failed: %d" % rc)
+    out = Encoded()
+    out.W8, out.H8, out.n_blocks, out.n_bits = res.W8, res.H8, res.n_blocks, res.n_bits
+    out.bits = np.ctypeslib.as_array(res.bits, (res.bits_bytes,)).copy()
+    N = res.n_blocks
+    out.zigzag = np.ctypeslib.as_array(res.zigzag, (3 * N, 64)).copy() if res.zigzag else None
+    out.unit_bits = np.ctypeslib.as_array(res.unit_bits, (3 * N,)).copy() if res.unit_bits else None
     oracle().orc_result_free(C.byref(res))
     return out
 

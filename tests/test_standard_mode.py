@@ -1,0 +1,187 @@
+"""Standard mode: a decodable baseline JPEG.  NOT a behaviour of the
+reference -- parity unpinned by it.  The mode is defined in integer arithmetic
+(tests/golden/std_dct_q39.i64 = the true DCT-II rounded to 2^-39; round-half-away
+quantisation; round-to-nearest colour conversion), so the checker in oracle/ and the HIP
+path must agree bit for bit; what ties it to the outside world is that libjpeg (PIL)
+decodes the files to the picture an independent JPEG encoder produces."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import GOLD
+
+PIL = pytest.importorskip("PIL.Image")
+
+KEEP = ol.KEEP_ZIGZAG | ol.KEEP_UNIT_BITS
+
+
+def psnr(a, b):
+    mse = ((a.astype(np.float64) - b.astype(np.float64)) ** 2).mean()
+    return 10 * np.log10(255.0 ** 2 / mse)
+
+
+def smooth_frame(W, H, seed=0):
+    """A picture with natural-ish statistics (smooth gradients + a little texture)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:H, 0:W]
+    img = np.stack([127 + 120 * np.sin(x / 37.0 + seed) * np.cos(y / 23.0),
+                    127 + 100 * np.cos(x / 51.0) * np.cos(y / 17.0 + 1),
+                    (x * 255 // max(W - 1, 1) + y * 255 // max(H - 1, 1)) / 2], -1)
+    img += rng.normal(0, 3, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def pil_decode(data):
+    return np.asarray(PIL.open(io.BytesIO(data)).convert("RGB"))
+
+
+def pil_encode(rgb, ql, qc):
+    buf = io.BytesIO()  # Pillow takes the tables in natural order and writes them zig-zagged
+    PIL.fromarray(rgb).save(buf, "JPEG", subsampling=0,
+                            qtables=[[int(v) for v in ql.reshape(64)], [int(v) for v in qc.reshape(64)]])
+    return buf.getvalue()
+
+
+def test_dct_table_is_the_true_dct():
+    """The defining table equals 1/4 a(u) a(v) cos cos * 2^39 (zig-zag row order) to the unit."""
+    T = ol.std_dct_table()
+    zz = ol.zigzag_order()
+    a = np.array([np.sqrt(0.5)] + [1.0] * 7)
+    k = np.arange(8)
+    C = np.cos((2 * k[:, None] + 1) * k[None, :] * np.pi / 16)  # [x][u]
+    for R in range(64):
+        v, u = divmod(int(zz[R]), 8)
+        want = (a[u] * a[v] / 4) * np.outer(C[:, v], C[:, u]).reshape(64) * 2.0 ** 39
+        assert np.abs(T[R] - want).max() <= 1.0
+    assert (T[0] == 1 << 36).all()
+
+
+@pytest.mark.parametrize("quality", [50, 75, 90])
+def test_oracle_standard_files_decode_like_an_independent_encoder(quality):
+    rgb = ol.read_ppm(os.path.join(GOLD, "fruit.ppm"))
+    ql, qc = ol.quant_tables(quality)
+    o = ol.oracle_std_encode(rgb, ql, qc)
+    H, W, _ = rgb.shape
+    f = ol.jfif_frame(o.bits, o.n_bits, W, H, ql, qc)
+    ours = pil_decode(f)
+    theirs = pil_decode(pil_encode(rgb, ql, qc))
+    assert ours.shape == rgb.shape
+    # same tables, same sampling: both decode to nearly the same picture (libjpeg's integer DCT and
+    # colour conversion round differently; fruit.ppm is close to noise, so that is the worst case) and
+    # both are equally far from the source
+    assert psnr(ours, theirs) > 30.0
+    assert abs(psnr(ours, rgb) - psnr(theirs, rgb)) < 0.1
+
+
+def test_oracle_standard_coefficients_against_float_dct():
+    """Independent arithmetic: scipy's orthonormal fp64 DCT-II of the same samples, divided and
+    rounded half away, gives the same integers except within 1e-6 of a rounding tie."""
+    import scipy.fft
+    rgb = smooth_frame(96, 64, 9)
+    rgb[:32] = ol.lcg_frame(96, 32, 5)  # some noise blocks as well
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    ycc = np.stack([np.minimum(255, (299 * r + 587 * g + 114 * b + 500) // 1000),
+                    np.minimum(255, (128000000 + 500000 * b - 168736 * r - 331264 * g + 500000) // 1000000),
+                    np.minimum(255, (128000000 + 500000 * r - 418688 * g - 81312 * b + 500000) // 1000000)], -1)
+    zz = ol.zigzag_order()
+    for q in (50, 90, 100):
+        ql, qc = ol.quant_tables(q)
+        o = ol.oracle_std_encode(rgb, ql, qc, KEEP)
+        N = o.n_blocks
+        for c in range(3):
+            blocks = (ycc[..., c] - 128.0).reshape(8, 8, 12, 8).transpose(0, 2, 1, 3).reshape(N, 8, 8)
+            coef = scipy.fft.dctn(blocks, type=2, norm="ortho", axes=(1, 2)).reshape(N, 64)[:, zz]
+            z = coef / (ql if c == 0 else qc).reshape(64)[zz].astype(np.float64)
+            want = np.sign(z) * np.floor(np.abs(z) + 0.5)
+            got = o.zigzag[c * N:(c + 1) * N]
+            bad = got != want
+            assert np.all(np.abs(np.abs(z[bad]) % 1.0 - 0.5) < 1e-6), (q, c, int(bad.sum()))
+
+
+def test_oracle_standard_eob_and_tables():
+    """EOB is omitted after a non-zero coefficient 63; run 3 / size 4 uses the 16-bit Annex K code."""
+    rgb = ol.lcg_frame(64, 64, 3)
+    ql, qc = ol.quant_tables(95)
+    o = ol.oracle_std_encode(rgb, ql, qc, KEEP)
+    strict_like = ol.oracle_entropy(o.zigzag)  # the reference's entropy rules on the same coefficients
+    n63 = int((o.zigzag[:, 63] != 0).sum())
+    assert n63 > 0
+    # every unit with c63 != 0 saves its 4-bit EOB (luma 1010 / chroma 00 -> 4 or 2 bits)
+    N = o.n_blocks
+    saved = 4 * int((o.zigzag[:N, 63] != 0).sum()) + 2 * int((o.zigzag[N:, 63] != 0).sum())
+    assert o.n_bits <= strict_like[1] - saved  # further savings: one bit per 17-bit typo hit
+    assert o.n_bits == int(o.unit_bits.sum())
+
+
+# ------------------------------------------------------------------------------ GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,q,kind", [(253, 254, 50, "fruit"), (640, 360, 50, "lcg"), (100, 37, 90, "lcg"),
+                                        (1920, 1080, 75, "smooth"), (8, 8, 100, "lcg"), (333, 65, 25, "smooth"),
+                                        (512, 512, 100, "lcg")])
+def test_gpu_standard_mode_equals_checker(jpeg, enc, W, H, q, kind):
+    rgb = (ol.read_ppm(os.path.join(GOLD, "fruit.ppm")) if kind == "fruit"
+           else ol.lcg_frame(W, H, 7) if kind == "lcg" else smooth_frame(W, H, 2))
+    ql, qc = ol.quant_tables(q)
+    enc.set_quant(ql, qc)
+    o = ol.oracle_std_encode(rgb, ql, qc, KEEP)
+    cf = enc.probe_coefficients(rgb, jpeg.F_STANDARD)
+    assert np.array_equal(cf.astype(np.int32), o.zigzag)
+    bits, nb = enc.encode_scan(rgb, jpeg.F_STANDARD)
+    assert nb[0] == o.n_bits
+    assert np.array_equal(bits[0], o.bits)
+    # MI355_F_CDS is ignored in standard mode (4:4:4)
+    bits2, nb2 = enc.encode_scan(rgb, jpeg.F_STANDARD | jpeg.F_CDS)
+    assert nb2[0] == nb[0] and np.array_equal(bits2[0], bits[0])
+    enc.set_quality(50)
+
+
+@pytest.mark.gpu
+def test_gpu_standard_jfif_decodes(jpeg, enc):
+    rgb = smooth_frame(640, 480, 5)
+    ql, qc = ol.quant_tables(85)
+    enc.set_quant(ql, qc)
+    got = enc.encode_jfif(rgb, jpeg.F_STANDARD)
+    o = ol.oracle_std_encode(rgb, ql, qc)
+    assert got == ol.jfif_frame(o.bits, o.n_bits, 640, 480, ql, qc)
+    dec = pil_decode(got)
+    assert psnr(dec, rgb) > 35.0
+    assert psnr(dec, pil_decode(pil_encode(rgb, ql, qc))) > 45.0
+    enc.set_quality(50)
+
+
+@pytest.mark.gpu
+def test_gpu_standard_second_look_is_exact(jpeg, monkeypatch):
+    """With the first look disabled (debug margin factor) every coefficient is decided by the
+    exact integer second look; nothing may change and nothing goes to the fix-up kernel."""
+    monkeypatch.setenv("MI355_JPEG_SCREEN_TAU_SCALE", "1e9")
+    e2 = jpeg.Encoder(0)
+    for (W, H, q) in [(320, 200, 50), (100, 37, 92)]:
+        rgb = ol.lcg_frame(W, H, 11)
+        ql, qc = ol.quant_tables(q)
+        e2.set_quant(ql, qc)
+        o = ol.oracle_std_encode(rgb, ql, qc, KEEP)
+        assert np.array_equal(e2.probe_coefficients(rgb, jpeg.F_STANDARD).astype(np.int32), o.zigzag)
+        bits, nb = e2.encode_scan(rgb, jpeg.F_STANDARD)
+        assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits)
+    e2.close()
+
+
+@pytest.mark.gpu
+def test_gpu_standard_batch_and_strict_interleaved(jpeg, enc):
+    """Standard and strict calls on one context do not disturb each other; batches equal single frames."""
+    enc.set_quality(50)
+    ql, qc = ol.quant_tables(50)
+    frames = np.stack([ol.lcg_frame(256, 128, s) for s in (1, 2, 3)])
+    want_std = [ol.oracle_std_encode(f, ql, qc) for f in frames]
+    want_strict = [ol.oracle_encode(f) for f in frames]
+    for _ in range(2):
+        bits, nb = enc.encode_scan(frames, jpeg.F_STANDARD)
+        for f in range(3):
+            assert nb[f] == want_std[f].n_bits and np.array_equal(bits[f], want_std[f].bits)
+        bits, nb = enc.encode_scan(frames, jpeg.F_CDS)
+        for f in range(3):
+            assert nb[f] == want_strict[f].n_bits and np.array_equal(bits[f], want_strict[f].bits)

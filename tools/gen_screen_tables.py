@@ -149,6 +149,30 @@ def main():
     print("eps max %.3e, fixed-point bound %.3e, worst observed |chain - fixed| %.3e" % (eps.max(), fix_bound, worst))
     assert worst <= eps.max() + fix_bound
 
+    # ---- standard mode: the TRUE 8x8 DCT-II as the same kind of fixed-point map,
+    # L_std[(v,u)][(y,x)] = 1/4 a(u) a(v) cos((2x+1)u pi/16) cos((2y+1)v pi/16), rounded to 2^-39.
+    # Standard mode is DEFINED by this integer table (q = round-half-away(sum / (Q*2^39)) in exact
+    # integer arithmetic), so GPU and test oracle agree bit for bit by construction.
+    import mpmath
+    mpmath.mp.dps = 60
+    std = np.zeros((64, 64), np.int64)
+    for R in range(64):
+        nat = ZIGZAG[R]
+        v, u = nat // 8, nat % 8
+        for k in range(64):
+            y, x = k // 8, k % 8
+            au = mpmath.sqrt(mpmath.mpf(1) / 2) if u == 0 else mpmath.mpf(1)
+            av = mpmath.sqrt(mpmath.mpf(1) / 2) if v == 0 else mpmath.mpf(1)
+            val = au * av / 4 * mpmath.cos((2 * x + 1) * u * mpmath.pi / 16) * mpmath.cos((2 * y + 1) * v * mpmath.pi / 16)
+            std[R, k] = int(mpmath.nint(val * (1 << FRAC_BITS)))
+    assert (std[0] == 1 << (FRAC_BITS - 3)).all()  # row 0 is exactly 1/8: DC = sum/8
+    std_limb = np.zeros((NLIMB, 64, 64), np.int8)
+    for R in range(64):
+        for k in range(64):
+            for l, d in enumerate(limbs_of(int(std[R, k]))):
+                std_limb[l, R, k] = d
+    std.astype("<i8").tofile(os.path.join(ROOT, "tests", "golden", "std_dct_q39.i64"))
+
     out = os.path.join(ROOT, "jpeg-encoder-opencl_amd", "csrc", "jpeg_screen_tables.h")
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_screen_tables.py -- do not edit.\n")
@@ -170,6 +194,13 @@ def main():
             f.write("  {\n")
             for R in range(64):
                 f.write("    {" + ",".join(str(int(v)) for v in limb[l, R]) + "},\n")
+            f.write("  },\n")
+        f.write("};\n\n// standard mode: the true DCT-II, same format (rows in zig-zag order)\n")
+        f.write("static const int8_t kStdLimb[%d][64][64] = {\n" % NLIMB)
+        for l in range(NLIMB):
+            f.write("  {\n")
+            for R in range(64):
+                f.write("    {" + ",".join(str(int(v)) for v in std_limb[l, R]) + "},\n")
             f.write("  },\n")
         f.write("};\n\n}  // namespace mi355\n")
     print("wrote", out)
