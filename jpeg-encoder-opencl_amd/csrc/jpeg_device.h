@@ -49,8 +49,8 @@ struct ScreenParams {
 uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves);
 hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,
                                 bool probe, uint32_t grid_waves, hipStream_t s);
-hipError_t launch_fixup(const Geom& g, const uint8_t* rgb, const ScreenParams& sp, bool probe,
-                        uint32_t grid_waves, hipStream_t s);
+hipError_t launch_fixup(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp, bool probe,
+                        hipStream_t s);
 hipError_t launch_meta_sizes(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* lut,
                              uint32_t* unit_off, uint32_t* tile_bits, uint32_t* status, hipStream_t s);
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,

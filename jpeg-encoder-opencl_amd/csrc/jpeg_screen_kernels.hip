@@ -601,23 +601,6 @@ __global__ void __launch_bounds__(256, 2)
         }
         const bool fast = g.fast_rows && __all(interior);
 
-        // The DC difference of lane 0 needs the last block of the previous tile: its DC is
-        // recomputed from its 64 samples, one pixel per lane.  When that block lies inside the
-        // image its three bytes per lane are fetched NOW and consumed after the walk.
-        uint32_t pbx = 0, pby = 0, pr = 0, pg = 0, pbl = 0;
-        bool pred_fast = false;
-        if (tile > 0) {
-            const uint32_t pb = tile * 64 - 1;
-            pby = pb / g.nbx;
-            pbx = pb - pby * g.nbx;
-            pred_fast = (pbx * 8 + 8 <= g.W) && (pby * 8 + 8 <= g.H);
-            if (pred_fast) {
-                const uint8_t* pp = f + ((size_t)(pby * 8 + (lane >> 3)) * g.W + pbx * 8 + (lane & 7)) * 3;
-                pr = pp[0];
-                pg = pp[1];
-                pbl = pp[2];
-            }
-        }
         STAMP(0);
 
         s_flag[lane] = 0;
@@ -627,6 +610,7 @@ __global__ void __launch_bounds__(256, 2)
 
         // raw RGB of unit-tile j+1 is fetched while unit-tile j is processed
         uint32_t raw[12];
+        uint32_t dcsum = 0;  // sample sum of the block whose coefficient 0 this lane will form
         if (fast) load_raw_rowpair(f, g, bxs[0], bys[0], gq, raw);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -665,18 +649,8 @@ __global__ void __launch_bounds__(256, 2)
             const v4i B = v4i{(int)(pk[0] ^ 0x80808080u), (int)(pk[1] ^ 0x80808080u),
                               (int)(pk[2] ^ 0x80808080u), (int)(pk[3] ^ 0x80808080u)};
 
-            // exact coefficient 0.  Strict: c0 = fl(sum * SCALE_00), q0 = round(c0 / Q0) (utils.cpp:336,459).
-            // Standard: row 0 of the true DCT is exactly 1/8, q0 = round-half-away(sum / (8 Q0)) in integers.
-            int q0;
-            if constexpr (STD) {
-                const int sl = (int)ssum - 8192;
-                const uint32_t Q0 = (uint32_t)sp.qd[ct * 64], a0 = (uint32_t)(sl < 0 ? -sl : sl);
-                const int n0 = (int)((a0 + 4u * Q0) / (8u * Q0));
-                q0 = sl < 0 ? -n0 : n0;
-            } else {
-                const double c0 = (double)((int)ssum - 8192) * kScale00;
-                q0 = (int)__builtin_round(c0 / sp.qd[ct * 64]);
-            }
+            // coefficient 0 is formed exactly after this loop, by the lane (n, gq == j) for unit 16j+n
+            if (gq == (uint32_t)j) dcsum = ssum;
 
             bool amb = false;
             uint32_t nzlo = 0, nzhi = 0;  // this lane's part of the unit's non-zero mask
@@ -717,10 +691,7 @@ __global__ void __launch_bounds__(256, 2)
                 for (int r = 0; r < 4; ++r) {
                     qb[r] = __float_as_uint(aa[r]);  // 0x4B400000 + q
                     a1[r] = !(__builtin_fmaf(__builtin_fabsf(zz[r]), 0x1p-21f, __builtin_fabsf(dd[r])) < qf[4 + r]);
-                    if (mt == 0 && r == 0 && gq == 0) {
-                        qb[r] = (uint32_t)q0;  // coefficient 0 is formed exactly
-                        a1[r] = false;
-                    }
+                    if (mt == 0 && r == 0 && gq == 0) a1[r] = false;  // coefficient 0: overwritten below
                 }
                 if (__any(a1[0] || a1[1] || a1[2] || a1[3])) {
                     // second look in fp64 with the least significant digit included (wave-uniform, rare)
@@ -764,6 +735,22 @@ __global__ void __launch_bounds__(256, 2)
             atomicOr(&s_mhi[16 * j + n], nzhi << (4 * gq));
             if (amb) s_flag[16 * j + n] = 1;
         }
+        {
+            // exact coefficient 0 of unit 16*gq + n.  Strict: c0 = fl(sum * SCALE_00), q0 = round(c0 / Q0)
+            // (utils.cpp:336,459).  Standard: row 0 of the true DCT is exactly 1/8,
+            // q0 = round-half-away(sum / (8 Q0)) in integers.
+            int q0;
+            if constexpr (STD) {
+                const int sl = (int)dcsum - 8192;
+                const uint32_t Q0 = (uint32_t)sp.qd[ct * 64], a0 = (uint32_t)(sl < 0 ? -sl : sl);
+                const int n0 = (int)((a0 + 4u * Q0) / (8u * Q0));
+                q0 = sl < 0 ? -n0 : n0;
+            } else {
+                const double c0 = (double)((int)dcsum - 8192) * kScale00;
+                q0 = (int)__builtin_round(c0 / sp.qd[ct * 64]);
+            }
+            reinterpret_cast<i16a*>(&s_tbuf[(16 * gq + n) * 33])[0] = (int16_t)q0;
+        }
         __builtin_amdgcn_wave_barrier();
         STAMP(1);
 
@@ -793,41 +780,15 @@ __global__ void __launch_bounds__(256, 2)
         if (!active || flagged) nw = 0;
 
         // Total bits of the unit = DC symbol + AC string.  The DC difference needs the previous
-        // block of the same channel: the neighbouring lane, or for lane 0 the last block of the
-        // previous tile, whose DC (always the exact fl(sum*SCALE_00)/Q0 form) is recomputed here
-        // from its 64 samples, one per lane.  Tile sums are accumulated with one atomic per wave
-        // (units left to k_fixup add themselves there).
+        // block of the same channel: the neighbouring lane.  Lane 0's predecessor is the last block
+        // of the previous tile, which another wave owns: its DC symbol is left out here and added
+        // by k_fixup from the DCs in `meta` (every DC there is exact).  Tile sums are
+        // accumulated with one atomic per wave (units left to k_fixup add themselves there).
         {
-            int pred0 = 0;
-            if (tile > 0) {
-                uint32_t sm;
-                if (pred_fast) {
-                    sm = chan == 0 ? csc_int<STD>(0, pr, pg, pbl)
-                                   : (chan == 1 ? csc_int<STD>(1, pr, pg, pbl) : csc_int<STD>(2, pr, pg, pbl));
-                    if (avg) {  // 2x2 mean of the quad (lane = y*8+x: partners x^1, y^1)
-                        uint32_t s4 = sm + (uint32_t)__shfl_xor((int)sm, 1);
-                        s4 += (uint32_t)__shfl_xor((int)s4, 8);
-                        sm = s4 >> 2;
-                    }
-                } else {
-                    sm = sample_generic_int<STD>(f, g, (int)chan, avg, pbx * 8 + (lane & 7), pby * 8 + (lane >> 3));
-                }
-                sm = wave_sum(sm);
-                if constexpr (STD) {
-                    const int sl = (int)sm - 8192;
-                    const uint32_t Q0 = (uint32_t)sp.qd[ct * 64], a0 = (uint32_t)(sl < 0 ? -sl : sl);
-                    const int n0 = (int)((a0 + 4u * Q0) / (8u * Q0));
-                    pred0 = sl < 0 ? -n0 : n0;
-                } else {
-                    const double pc0 = (double)((int)sm - 8192) * kScale00;
-                    pred0 = (int)__builtin_round(pc0 / sp.qd[ct * 64]);
-                }
-            }
-            int pred = __shfl_up(dc, 1);
-            if (lane == 0) pred = pred0;
+            const int pred = __shfl_up(dc, 1);
             uint32_t ubits = aclen;
             auto count = [&](uint32_t, uint32_t len) { ubits += len; };
-            const bool dc_ok = put_dc(dc - pred, s_dc[ct], count);
+            const bool dc_ok = lane == 0 || put_dc(dc - pred, s_dc[ct], count);
             if (!dc_ok && active) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
             if (!active || flagged) ubits = 0;
             ubits = wave_sum(ubits);
@@ -876,7 +837,7 @@ __global__ void __launch_bounds__(256, 2)
 // ----------------------------------------------------------------------------
 template <bool PROBE>
 __global__ void __launch_bounds__(64)
-    k_fixup(Geom g, const uint8_t* __restrict__ rgb, ScreenParams sp) {
+    k_fixup(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
     __shared__ uint32_t s_slot[kSlotWordsFull * 64];
     __shared__ uint32_t s_act[2][256];
     __shared__ uint32_t s_smp[16 * 64];
@@ -944,16 +905,31 @@ __global__ void __launch_bounds__(64)
             }
             const int dc = (int)(int16_t)(c[0] & 0xffffu);
             sp.meta[us] = make_uint2(off, (aclen << 16) | ((uint32_t)dc & 0xffffu));
-            // this unit's share of the tile sum (k_screen_encode left it out); every DC in meta is exact
-            int pred = 0;
-            if (ul > 0) pred = meta_dc(sp.meta[us - 1].y);
-            else if (tile > 0) pred = meta_dc(sp.meta[(((size_t)frame * g.tiles + tile - 1) * 3 + chan) * 64 + 63].y);
+            // this unit's share of the tile sum (k_screen_encode left it out); every DC in meta is exact.
+            // The DC symbol of a tile's first unit is added by the loop at the end of this kernel.
             uint32_t ubits = aclen;
-            auto count = [&](uint32_t, uint32_t len) { ubits += len; };
-            if (!put_dc(dc - pred, s_dcf[chan ? 1 : 0], count)) atomicOr(sp.status, 1u);
+            if (ul > 0) {
+                const int pred = meta_dc(sp.meta[us - 1].y);
+                auto count = [&](uint32_t, uint32_t len) { ubits += len; };
+                if (!put_dc(dc - pred, s_dcf[chan ? 1 : 0], count)) atomicOr(sp.status, 1u);
+            }
             atomicAdd(&sp.tile_bits[(size_t)frame * g.tiles + tile], ubits);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    // DC symbol of each tile's first unit, per channel: its predecessor is the last block of the
+    // previous tile, encoded by another wave of k_screen_encode, which therefore left the symbol
+    // out of the tile sum.  Every DC in `meta` is exact already (fix-ups rewrite the same value).
+    const uint32_t heads = n_frames * g.tiles * 3;
+    for (uint32_t p = blockIdx.x * 64 + lane; p < heads; p += gridDim.x * 64) {
+        const uint32_t ft = p / 3, c = p - ft * 3, tile = ft % g.tiles;
+        const size_t u0 = (size_t)p * 64;  // ((frame * tiles + tile) * 3 + c) * 64
+        const int dc = meta_dc(sp.meta[u0].y);
+        const int pred = tile > 0 ? meta_dc(sp.meta[u0 - 192 + 63].y) : 0;
+        uint32_t len = 0;
+        auto count = [&](uint32_t, uint32_t l) { len += l; };
+        if (!put_dc(dc - pred, s_dcf[c ? 1 : 0], count)) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
+        atomicAdd(&sp.tile_bits[ft], len);
     }
 }
 
@@ -1134,12 +1110,16 @@ hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t*
         hipLaunchKernelGGL((k_screen_encode<false, false>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
     return hipGetLastError();
 }
-hipError_t launch_fixup(const Geom& g, const uint8_t* rgb, const ScreenParams& sp, bool probe,
-                        uint32_t grid_waves, hipStream_t s) {
+hipError_t launch_fixup(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp, bool probe,
+                        hipStream_t s) {
+    // one lane per (tile, channel) head when the batch is small, a few per lane when it is large
+    const uint64_t heads = (uint64_t)n_frames * g.tiles * 3;
+    uint32_t grid_waves = (uint32_t)((heads + 63) / 64 < 2048 ? (heads + 63) / 64 : 2048);
+    if (grid_waves < 32) grid_waves = 32;
     if (probe)
-        hipLaunchKernelGGL((k_fixup<true>), dim3(grid_waves), dim3(64), 0, s, g, rgb, sp);
+        hipLaunchKernelGGL((k_fixup<true>), dim3(grid_waves), dim3(64), 0, s, g, n_frames, rgb, sp);
     else
-        hipLaunchKernelGGL((k_fixup<false>), dim3(grid_waves), dim3(64), 0, s, g, rgb, sp);
+        hipLaunchKernelGGL((k_fixup<false>), dim3(grid_waves), dim3(64), 0, s, g, n_frames, rgb, sp);
     return hipGetLastError();
 }
 hipError_t launch_meta_sizes(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* lut,

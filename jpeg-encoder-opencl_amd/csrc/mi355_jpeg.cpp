@@ -444,7 +444,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     record(c, 0, s);
     HIP_TRY(launch_screen_encode(g, n_frames, d_rgb, sp, false, c->screen_waves, s));
     record(c, 1, s);
-    HIP_TRY(launch_fixup(g, d_rgb, sp, false, 32, s));
+    HIP_TRY(launch_fixup(g, n_frames, d_rgb, sp, false, s));
     record(c, 2, s);  // slot [1,2] = exact fix-up (tile sums are accumulated by the encode kernel itself)
     HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
                              c->d_status, c->d_counters, true, s));
@@ -466,7 +466,7 @@ int run_screened_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, u
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(uint32_t), s));
     HIP_TRY(hipMemsetAsync(c->d_tile_bits, 0, (size_t)g.tiles * sizeof(uint32_t), s));
     HIP_TRY(launch_screen_encode(g, 1, d_rgb, sp, true, c->screen_waves, s));
-    HIP_TRY(launch_fixup(g, d_rgb, sp, true, 32, s));
+    HIP_TRY(launch_fixup(g, 1, d_rgb, sp, true, s));
     // leave the accumulators re-armed for the next encode call
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(uint32_t), s));
     HIP_TRY(hipMemsetAsync(c->d_tile_bits, 0, (size_t)g.tiles * sizeof(uint32_t), s));
