@@ -639,6 +639,7 @@ __global__ void __launch_bounds__(256, 2)
                     }
                 }
             }
+            STAMP(5);
             // sum of the block's 64 samples (for the exact DC): 16 in this lane, then over the 4 row-pair lanes
             uint32_t ssum = 0;
 #pragma unroll
@@ -734,6 +735,7 @@ __global__ void __launch_bounds__(256, 2)
             atomicOr(&s_mlo[16 * j + n], nzlo << (4 * gq));
             atomicOr(&s_mhi[16 * j + n], nzhi << (4 * gq));
             if (amb) s_flag[16 * j + n] = 1;
+            STAMP(6);
         }
         {
             // exact coefficient 0 of unit 16*gq + n.  Strict: c0 = fl(sum * SCALE_00), q0 = round(c0 / Q0)

@@ -673,8 +673,8 @@ int mi355_jpeg_sync(mi355_jpeg_ctx* c, void* stream) {
         double sum[8] = {0};
         for (int w = 0; w < 2048; ++w)
             for (int i = 0; i < 8; ++i) sum[i] += (double)h[(size_t)w * 8 + i];
-        fprintf(stderr, "[stamps] cycles per wave: setup %.0f | samples+mfma+post %.0f | walk %.0f | dc/sizes %.0f | arena+meta %.0f | loop %.0f\n",
-                sum[0] / 2048, sum[1] / 2048, sum[2] / 2048, sum[3] / 2048, sum[4] / 2048, sum[7] / 2048);
+        fprintf(stderr, "[stamps] cycles per wave: setup %.0f | samples %.0f | mfma+quantise %.0f | dc0+barrier %.0f | walk %.0f | dc/sizes %.0f | arena+meta %.0f | loop %.0f\n",
+                sum[0] / 2048, sum[5] / 2048, sum[6] / 2048, sum[1] / 2048, sum[2] / 2048, sum[3] / 2048, sum[4] / 2048, sum[7] / 2048);
     }
 #endif
     uint32_t st = 0;
