@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--ring", type=int, default=8, help="distinct resident frames per rank")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams (one encode context each) the steps alternate over, so that the small "
                          "tail kernels of one frame overlap the block-encode kernel of the next")
     ap.add_argument("--no-cpu-baseline", action="store_true")
