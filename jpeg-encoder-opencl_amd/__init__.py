@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libmi355jpeg.so")
 
 F_CDS = 1
 F_STANDARD = 2  # decodable baseline JPEG (not a behaviour of the reference), see include/mi355_jpeg.h
+F_420 = 4       # with F_STANDARD: real 4:2:0 MCUs
 F_DEFAULT = F_CDS
 
 OK, E_ARG, E_NO_DEVICE, E_CAPACITY, E_CATEGORY, E_ALLOC, E_TABLE, E_HIP = 0, -1, -2, -3, -4, -5, -6, -100
@@ -240,8 +241,11 @@ class Encoder:
     def probe_coefficients(self, rgb, flags=F_DEFAULT):
         rgb = np.ascontiguousarray(rgb, np.uint8)
         H, W, _ = rgb.shape
-        N = ((W + 7) // 8) * ((H + 7) // 8)
-        out = np.empty((3 * N, 64), np.int16)
+        if flags & F_420:
+            units = 6 * ((W + 15) // 16) * ((H + 15) // 16)
+        else:
+            units = 3 * ((W + 7) // 8) * ((H + 7) // 8)
+        out = np.empty((units, 64), np.int16)
         _check(lib().mi355_jpeg_probe_coefficients(self._h, rgb.ctypes.data, W, H, flags, out.ctypes.data))
         return out
 

@@ -14,11 +14,18 @@ struct Geom {
     uint32_t tiles;         // ceil(N/64)
     uint32_t flags;         // MI355_F_*
     uint32_t fast_rows;     // 1: W % 8 == 0 and the frame base is 8-byte aligned
+    uint32_t passes;        // wave passes per tile: 3 (one per channel); 6 in 4:2:0 standard mode
+                            // (four luma quarter-tiles of 16 MCUs, then Cb, then Cr)
+    uint32_t nmx;           // 4:2:0 only: MCUs (16x16) per row = W8/16; there N = MCUs per frame,
+                            // W8/H8 are multiples of 16 and a tile is 64 MCUs = 384 units of the scan
     uint64_t frame_stride;  // bytes between frames = W*H*3
 };
+inline bool is420(const Geom& g) { return g.passes == 6; }
+// units (8x8 blocks in the scan) per frame
+inline size_t unit_count(const Geom& g) { return (size_t)g.N * g.passes; }
 
 // Sizes of the device workspace per frame, in elements.
-inline size_t coef_dwords(const Geom& g) { return (size_t)g.tiles * 3 * 2048; }
+inline size_t coef_dwords(const Geom& g) { return (size_t)g.tiles * g.passes * 2048; }
 inline size_t unit_off_words(const Geom& g) { return (size_t)g.tiles * 192; }
 
 // Device pointers of the screened (integer-MFMA) pipeline, jpeg_screen_kernels.hip.

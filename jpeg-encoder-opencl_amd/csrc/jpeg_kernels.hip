@@ -308,10 +308,22 @@ __global__ void __launch_bounds__(192)
 __global__ void k_coefs_to_rows(Geom g, const uint32_t* __restrict__ coefs, int16_t* __restrict__ rows) {
     uint32_t unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // chan*N + block
     uint32_t k = threadIdx.x & 63;
-    if (unit >= 3 * g.N) return;
-    uint32_t chan = unit / g.N, b = unit - chan * g.N;
-    uint32_t tile = b >> 6, lane = b & 63;
-    uint32_t w = coefs[((size_t)tile * 3 + chan) * 2048 + (k >> 1) * 64 + lane];
+    if (unit >= g.passes * g.N) return;
+    uint32_t tile, pass, lane;
+    if (g.passes == 6) {
+        // 4:2:0 row order: luma 4*mcu + k, then Cb at 4M + mcu, Cr at 5M + mcu; in the tiled workspace a
+        // tile's 256 luma units are passes 0..3 back to back in that same order
+        if (unit < 4 * g.N) {
+            tile = unit >> 8, pass = (unit >> 6) & 3, lane = unit & 63;
+        } else {
+            uint32_t c = unit / g.N, m = unit - c * g.N;  // c = 4 (Cb), 5 (Cr)
+            tile = m >> 6, pass = c, lane = m & 63;
+        }
+    } else {
+        uint32_t b = unit % g.N;
+        pass = unit / g.N, tile = b >> 6, lane = b & 63;
+    }
+    uint32_t w = coefs[((size_t)tile * g.passes + pass) * 2048 + (k >> 1) * 64 + lane];
     rows[(size_t)unit * 64 + k] = (int16_t)((k & 1) ? (w >> 16) : (w & 0xffffu));
 }
 // reference row order int16 -> tiled coefs
@@ -381,7 +393,7 @@ hipError_t launch_emit(const Geom& g, uint32_t n_frames, const uint32_t* coefs, 
     return hipGetLastError();
 }
 hipError_t launch_coefs_to_rows(const Geom& g, const uint32_t* coefs, int16_t* rows, hipStream_t s) {
-    hipLaunchKernelGGL(k_coefs_to_rows, dim3((3 * g.N + 3) / 4), dim3(256), 0, s, g, coefs, rows);
+    hipLaunchKernelGGL(k_coefs_to_rows, dim3((g.passes * g.N + 3) / 4), dim3(256), 0, s, g, coefs, rows);
     return hipGetLastError();
 }
 hipError_t launch_rows_to_coefs(const Geom& g, const int16_t* rows, uint32_t* coefs, hipStream_t s) {

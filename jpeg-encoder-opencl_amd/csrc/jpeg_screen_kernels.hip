@@ -164,6 +164,67 @@ __device__ __forceinline__ void generic_rowpair(const uint8_t* __restrict__ f, c
     }
 }
 
+// ---- 4:2:0 standard mode: one chroma sample = rounded mean of the 2x2 converted samples ----
+// Raw RGB of pixel rows row0, row0+1 of MCU (mx,my): 2 x 48 bytes as twelve 8-byte loads (fast
+// path: every MCU of the wave interior, W % 8 == 0, base 8-aligned).
+__device__ __forceinline__ void load_raw_mcu_rows(const uint8_t* __restrict__ f, const Geom& g, uint32_t mx,
+                                                  uint32_t my, uint32_t row0, uint32_t (&w)[24]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint2* p = reinterpret_cast<const uint2*>(f + ((size_t)(my * 16 + row0 + r) * g.W + mx * 16) * 3);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            uint2 v = p[i];
+            w[r * 12 + 2 * i] = v.x;
+            w[r * 12 + 2 * i + 1] = v.y;
+        }
+    }
+}
+// One row of 8 chroma samples of channel CHAN from two pixel rows of 16, packed 4 per dword.
+template <int CHAN>
+__device__ __forceinline__ void convert_chroma420_row(const uint32_t (&w)[24], uint32_t (&pk2)[2]) {
+    uint32_t m[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        uint32_t sum = 2u;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t c[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    int byte = 3 * (2 * x + h) + k;
+                    c[k] = (w[r * 12 + (byte >> 2)] >> (8 * (byte & 3))) & 255u;
+                }
+                sum += csc_int<true>(CHAN, c[0], c[1], c[2]);
+            }
+        m[x] = sum >> 2;
+    }
+    pk2[0] = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
+    pk2[1] = m[4] | (m[5] << 8) | (m[6] << 16) | (m[7] << 24);
+}
+// Edge MCUs: one chroma sample at a time, every contributing pixel mirrored on its own
+// (the checker pads the converted image, then averages).
+__device__ __forceinline__ void generic_chroma420(const uint8_t* __restrict__ f, const Geom& g, int chan,
+                                                  uint32_t mx, uint32_t my, uint32_t gq, uint32_t (&pk)[4]) {
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        uint32_t v = 0;
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int sidx = i * 4 + j;  // 0..15 within the chroma row pair 2gq, 2gq+1
+            const uint32_t px = mx * 16 + 2 * (sidx & 7), py = my * 16 + 2 * (gq * 2 + (sidx >> 3));
+            const uint32_t sum = sample_generic_int<true>(f, g, chan, false, px, py) +
+                                 sample_generic_int<true>(f, g, chan, false, px + 1, py) +
+                                 sample_generic_int<true>(f, g, chan, false, px, py + 1) +
+                                 sample_generic_int<true>(f, g, chan, false, px + 1, py + 1) + 2u;
+            v |= (sum >> 2) << (8 * j);
+        }
+        pk[i] = v;
+    }
+}
+
 // ----------------------------------------------------------------------------
 // device-side parameter block
 // ----------------------------------------------------------------------------
@@ -496,9 +557,14 @@ constexpr uint32_t kEncWaves = 4;
 #define STAMP(i) do { } while (0)
 #endif
 
-template <bool PROBE, bool STD>
+// MODE 0: strict (the reference's arithmetic); 1: standard 4:4:4; 2: standard 4:2:0 (tile = 64 MCUs,
+// six passes: luma quarter-tiles 0..3 -- unit u of pass s is block k = u & 3 of MCU 16 s + u / 4, i.e.
+// the scan order of the luma blocks -- then Cb, Cr with one block per MCU).
+template <bool PROBE, int MODE>
 __global__ void __launch_bounds__(256, 2)
     k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
+    constexpr bool STD = MODE != 0, S420 = MODE == 2;
+    constexpr uint32_t kPasses = S420 ? 6u : 3u;
     __shared__ uint32_t s_tbuf_all[kEncWaves][64 * 33];            // zig-zag rows, int16 pairs, stride 33 dwords
     __shared__ uint32_t s_slot_all[kEncWaves][(kSlotRows + 1) * 64];  // AC strings [word][lane] + dump row
     __shared__ uint32_t s_mask_all[kEncWaves][2][64];              // non-zero masks (lo, hi)
@@ -540,13 +606,13 @@ __global__ void __launch_bounds__(256, 2)
     // that the three channels of a tile are processed side by side in one XCD and share its
     // RGB bytes in that L2.  Speed only: any mapping is correct.
     const uint32_t gwave = blockIdx.x * kEncWaves + wv;   // global wave id
-    const uint32_t per_frame = g.tiles * 3;
+    const uint32_t per_frame = g.tiles * kPasses;
     const bool xcd_map = (gridDim.x % 8u) == 0u;
     const uint32_t xcd = blockIdx.x % 8u;
     const uint32_t local = (blockIdx.x / 8u) * kEncWaves + wv;       // index of this wave inside its XCD
     const uint32_t local_n = (gridDim.x / 8u) * kEncWaves;           // waves per XCD
     const uint32_t tiles_x = xcd_map ? (g.tiles + 7u - xcd) / 8u : 0u;  // tiles this XCD owns per frame
-    const uint32_t pairs_total = xcd_map ? tiles_x * 3u * n_frames : per_frame * n_frames;
+    const uint32_t pairs_total = xcd_map ? tiles_x * kPasses * n_frames : per_frame * n_frames;
     const uint32_t pstart = xcd_map ? local : gwave;
     const uint32_t pstep = xcd_map ? local_n : gridDim.x * kEncWaves;
 
@@ -559,27 +625,58 @@ __global__ void __launch_bounds__(256, 2)
         STAMP(7);
         uint32_t frame, tile, chan;
         if (xcd_map) {
-            const uint32_t pf = tiles_x * 3u;
+            const uint32_t pf = tiles_x * kPasses;
             frame = p / pf;
             const uint32_t q = p - frame * pf;
-            tile = (q / 3u) * 8u + xcd;
-            chan = q % 3u;
+            tile = (q / kPasses) * 8u + xcd;
+            chan = q % kPasses;
         } else {
             frame = p / per_frame;
             const uint32_t q = p - frame * per_frame;
-            tile = q / 3u;
-            chan = q % 3u;
+            tile = q / kPasses;
+            chan = q % kPasses;
         }
-        const uint32_t ct = chan ? 1u : 0u;
+        // `chan` is the pass; the colour component differs from it only in 4:2:0 (passes 0..3 = luma)
+        const uint32_t comp = S420 ? (chan < 4u ? 0u : chan - 3u) : chan;
+        const bool luma420 = S420 && chan < 4u, chroma420 = S420 && chan >= 4u;
+        const uint32_t ct = comp ? 1u : 0u;
         const uint8_t* f = rgb + (size_t)frame * g.frame_stride;
-        const bool avg = !STD && (chan != 0) && (g.flags & 1u);  // standard mode is 4:4:4
-        const size_t us_base = (((size_t)frame * g.tiles + tile) * 3 + chan) * 64;
+        const bool avg = !STD && (comp != 0) && (g.flags & 1u);  // standard mode never replicates chroma means
+        const size_t us_base = (((size_t)frame * g.tiles + tile) * kPasses + chan) * 64;
 
         // block coordinates of this lane's four blocks (16j + n), and whether the whole tile
         // lies inside the image (no mirror padding)
         uint32_t bxs[4], bys[4];
         bool interior = true;
-        {
+        if constexpr (S420) {
+            // MCU of this lane's unit in sub-tile j: luma pass s: 16 s + 4 j + n / 4 (block k = n & 3 of it),
+            // chroma pass: 16 j + n.  For chroma passes bxs/bys hold MCU coordinates.
+            const uint32_t step = luma420 ? 4u : 16u;
+            uint32_t m = tile * 64 + (luma420 ? 16 * chan + (n >> 2) : n);
+            uint32_t my = m / g.nmx, mx = m - my * g.nmx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (m >= g.N) {  // past the last MCU: any valid one will do, the lane is masked later
+                    mx = g.nmx - 1;
+                    my = g.N / g.nmx - 1;
+                }
+                if (luma420) {
+                    bxs[j] = 2 * mx + (n & 1);
+                    bys[j] = 2 * my + ((n >> 1) & 1);
+                    interior = interior && (bxs[j] * 8 + 8 <= g.W) && (bys[j] * 8 + 8 <= g.H);
+                } else {
+                    bxs[j] = mx;
+                    bys[j] = my;
+                    interior = interior && (mx * 16 + 16 <= g.W) && (my * 16 + 16 <= g.H);
+                }
+                m += step;
+                mx += step;
+                while (mx >= g.nmx) {
+                    mx -= g.nmx;
+                    ++my;
+                }
+            }
+        } else {
             uint32_t b = tile * 64 + n;
             uint32_t by = b / g.nbx, bx = b - by * g.nbx;
 #pragma unroll
@@ -611,25 +708,41 @@ __global__ void __launch_bounds__(256, 2)
         // raw RGB of unit-tile j+1 is fetched while unit-tile j is processed
         uint32_t raw[12];
         uint32_t dcsum = 0;  // sample sum of the block whose coefficient 0 this lane will form
-        if (fast) load_raw_rowpair(f, g, bxs[0], bys[0], gq, raw);
+        if (fast && !chroma420) load_raw_rowpair(f, g, bxs[0], bys[0], gq, raw);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t bx = bxs[j], by = bys[j];
             uint32_t pk[4];
-            if (fast) {
+            if (chroma420) {
+                if constexpr (S420) {  // rows 2gq, 2gq+1 of the MCU's 8x8 chroma block <- pixel rows 4gq .. 4gq+3
+                    if (fast) {
+#pragma unroll 1
+                        for (uint32_t half = 0; half < 2; ++half) {  // one chroma row at a time: 24 live dwords
+                            uint32_t w24[24], o[2];
+                            load_raw_mcu_rows(f, g, bx, by, 4 * gq + 2 * half, w24);
+                            if (comp == 1) convert_chroma420_row<1>(w24, o);
+                            else convert_chroma420_row<2>(w24, o);
+                            if (half == 0) pk[0] = o[0], pk[1] = o[1];
+                            else pk[2] = o[0], pk[3] = o[1];
+                        }
+                    } else {
+                        generic_chroma420(f, g, (int)comp, bx, by, gq, pk);
+                    }
+                }
+            } else if (fast) {
                 uint32_t cur[12];
 #pragma unroll
                 for (int i = 0; i < 12; ++i) cur[i] = raw[i];
                 if (j < 3) load_raw_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, raw);
-                if (chan == 0) convert_rowpair<0, STD>(cur, false, pk);
-                else if (chan == 1) convert_rowpair<1, STD>(cur, avg, pk);
+                if (comp == 0) convert_rowpair<0, STD>(cur, false, pk);
+                else if (comp == 1) convert_rowpair<1, STD>(cur, avg, pk);
                 else convert_rowpair<2, STD>(cur, avg, pk);
             } else {
-                if (chan == 0) generic_rowpair<0, STD>(f, g, false, bx, by, gq, pk);
-                else if (chan == 1) generic_rowpair<1, STD>(f, g, avg, bx, by, gq, pk);
+                if (comp == 0) generic_rowpair<0, STD>(f, g, false, bx, by, gq, pk);
+                else if (comp == 1) generic_rowpair<1, STD>(f, g, avg, bx, by, gq, pk);
                 else generic_rowpair<2, STD>(f, g, avg, bx, by, gq, pk);
             }
-            if constexpr (PROBE) {
+            if constexpr (PROBE && !S420) {
                 if (sp.samples && tile * 64 + 16 * j + n < g.N) {
 #pragma unroll
                     for (int sidx = 0; sidx < 16; ++sidx) {
@@ -757,7 +870,7 @@ __global__ void __launch_bounds__(256, 2)
         STAMP(1);
 
         // ---- walk phase: lane = block
-        const uint32_t b = tile * 64 + lane;
+        const uint32_t b = luma420 ? tile * 64 + 16 * chan + (lane >> 2) : tile * 64 + lane;  // block, or MCU in 4:2:0
         const bool active = b < g.N;
         bool flagged = s_flag[lane] != 0;
         const i16a* row16 = reinterpret_cast<const i16a*>(&s_tbuf[lane * 33]);
@@ -922,15 +1035,26 @@ __global__ void __launch_bounds__(64)
     // DC symbol of each tile's first unit, per channel: its predecessor is the last block of the
     // previous tile, encoded by another wave of k_screen_encode, which therefore left the symbol
     // out of the tile sum.  Every DC in `meta` is exact already (fix-ups rewrite the same value).
-    const uint32_t heads = n_frames * g.tiles * 3;
+    const uint32_t P = g.passes, heads = n_frames * g.tiles * P;
     for (uint32_t p = blockIdx.x * 64 + lane; p < heads; p += gridDim.x * 64) {
-        const uint32_t ft = p / 3, c = p - ft * 3, tile = ft % g.tiles;
-        const size_t u0 = (size_t)p * 64;  // ((frame * tiles + tile) * 3 + c) * 64
+        const uint32_t ft = p / P, c = p - ft * P, tile = ft % g.tiles;
+        const size_t u0 = (size_t)p * 64;  // ((frame * tiles + tile) * passes + c) * 64
+        int pred = 0;
+        bool luma = c == 0;
+        if (P == 6) {
+            // 4:2:0: luma quarter-tile c follows quarter-tile c - 1 (or the previous tile's quarter-tile 3);
+            // a quarter-tile past the last MCU has no units at all
+            luma = c < 4;
+            if (luma && tile * 64 + 16 * c >= g.N) continue;
+            if (luma && c > 0) pred = meta_dc(sp.meta[u0 - 64 + 63].y);
+            else if (tile > 0) pred = meta_dc(sp.meta[u0 - 6 * 64 + (luma ? 3 * 64 : 0) + 63].y);
+        } else if (tile > 0) {
+            pred = meta_dc(sp.meta[u0 - 192 + 63].y);
+        }
         const int dc = meta_dc(sp.meta[u0].y);
-        const int pred = tile > 0 ? meta_dc(sp.meta[u0 - 192 + 63].y) : 0;
         uint32_t len = 0;
         auto count = [&](uint32_t, uint32_t l) { len += l; };
-        if (!put_dc(dc - pred, s_dcf[c ? 1 : 0], count)) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
+        if (!put_dc(dc - pred, s_dcf[luma ? 0 : 1], count)) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
         atomicAdd(&sp.tile_bits[ft], len);
     }
 }
@@ -990,13 +1114,18 @@ __global__ void __launch_bounds__(192)
 // ----------------------------------------------------------------------------
 // k_merge: like k_emit, but the AC bits come ready-made from the arena.
 // ----------------------------------------------------------------------------
-__global__ void __launch_bounds__(192)
+// S420: the tile is 64 MCUs = 384 units; thread t = 6 * mcu + k is the unit at position t of the
+// tile's scan (k < 4: luma block k of the MCU = unit 4 mcu + k of the tile's 256 luma units, which the
+// encode kernel stored as pass (4 mcu + k) / 64, lane (4 mcu + k) % 64; k = 4, 5: Cb, Cr).
+template <bool S420>
+__global__ void __launch_bounds__(S420 ? 384 : 192)
     k_merge(Geom g, const uint2* __restrict__ meta, const uint32_t* __restrict__ arena,
             const uint32_t* __restrict__ lut, const uint64_t* __restrict__ tile_off,
             uint8_t* __restrict__ out, uint64_t out_stride, const uint32_t* __restrict__ status,
             uint32_t lds_words_limit) {
+    constexpr uint32_t NT = S420 ? 384 : 192, UPB = S420 ? 6 : 3;  // threads, units per scan step (block / MCU)
     __shared__ uint32_t s_dc[2][16];
-    __shared__ uint32_t s_bits[192];
+    __shared__ uint32_t s_bits[NT];
     __shared__ uint32_t s_words[kEmitLdsWords];
     const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
     const uint32_t tile = blockIdx.x, frame = blockIdx.y;
@@ -1011,45 +1140,75 @@ __global__ void __launch_bounds__(192)
     const bool last_tile = tile + 1 == g.tiles;
     if (tid < 32) s_dc[tid >> 4][tid & 15] = lut[(tid >> 4) * 256 + (tid & 15)];
     if (use_lds) {
-        for (uint32_t i = tid; i < nw; i += 192) s_words[i] = 0;
+        for (uint32_t i = tid; i < nw; i += NT) s_words[i] = 0;
     } else {
-        for (uint32_t i = tid; i < nw; i += 192) {
+        for (uint32_t i = tid; i < nw; i += NT) {
             bool shared = (i == 0 && (start & 31)) || (i == nw - 1 && (end & 31) && !last_tile);
             if (!shared) __hip_atomic_store(&outw[w0 + i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // this unit: DC, AC length, arena offset; the first words of its AC string are fetched now
-    const bool active = tile * 64 + lane < g.N;
-    const uint2 m = meta[((ft0 + tile) * 3 + chan) * 64 + lane];
-    const int dc = meta_dc(m.y);
+    bool active, chroma;
+    uint32_t spos;  // position of the unit in the tile's scan
+    uint2 m;
+    int dc, pred;
+    if constexpr (S420) {
+        const uint32_t mcu = tid / 6, k = tid - mcu * 6;
+        const size_t t0 = (ft0 + tile) * 6 * 64;
+        spos = tid;
+        chroma = k >= 4;
+        active = tile * 64 + mcu < g.N;
+        pred = 0;
+        if (!chroma) {
+            const uint32_t L = 4 * mcu + k;  // pass L >> 6, lane L & 63: slot t0 + L
+            m = meta[t0 + L];
+            if (L > 0) pred = meta_dc(meta[t0 + L - 1].y);
+            else if (tile > 0) pred = meta_dc(meta[t0 - 6 * 64 + 3 * 64 + 63].y);
+        } else {
+            const size_t slot = t0 + (size_t)k * 64 + mcu;
+            m = meta[slot];
+            if (mcu > 0) pred = meta_dc(meta[slot - 1].y);
+            else if (tile > 0) pred = meta_dc(meta[slot - 6 * 64 + 63].y);
+        }
+        dc = meta_dc(m.y);
+    } else {
+        spos = lane * 3 + chan;
+        chroma = chan != 0;
+        active = tile * 64 + lane < g.N;
+        m = meta[((ft0 + tile) * 3 + chan) * 64 + lane];
+        dc = meta_dc(m.y);
+        pred = meta_pred(meta, ft0, tile, chan, lane, dc);
+    }
     const uint32_t aclen = active ? (m.y >> 16) : 0u;
-    const int pred = meta_pred(meta, ft0, tile, chan, lane, dc);
     uint32_t pre[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) pre[i] = (uint32_t)i * 32u < aclen ? arena[m.x + i] : 0u;
     __syncthreads();
-    // tile-local exclusive offsets in scan order 3*block + chan
+    // tile-local exclusive offsets in scan order
     uint32_t dcl = 0;
     {
         auto count = [&](uint32_t, uint32_t len) { dcl += len; };
-        put_dc(dc - pred, s_dc[chan ? 1 : 0], count);
+        put_dc(dc - pred, s_dc[chroma ? 1 : 0], count);
     }
-    s_bits[lane * 3 + chan] = active ? dcl + aclen : 0u;
+    s_bits[spos] = active ? dcl + aclen : 0u;
     __syncthreads();
     if (tid < 64) {
-        uint32_t a0 = s_bits[tid * 3], a1 = s_bits[tid * 3 + 1], a2 = s_bits[tid * 3 + 2];
-        uint32_t incl = wave_incl_scan(a0 + a1 + a2, tid);
-        uint32_t excl = incl - (a0 + a1 + a2);
-        s_bits[tid * 3] = excl;
-        s_bits[tid * 3 + 1] = excl + a0;
-        s_bits[tid * 3 + 2] = excl + a0 + a1;
+        uint32_t a[UPB], sum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < UPB; ++i) a[i] = s_bits[tid * UPB + i], sum += a[i];
+        uint32_t run = wave_incl_scan(sum, tid) - sum;
+#pragma unroll
+        for (uint32_t i = 0; i < UPB; ++i) {
+            s_bits[tid * UPB + i] = run;
+            run += a[i];
+        }
     }
     __syncthreads();
     if (active) {
-        const uint64_t pos = (start & 31) + s_bits[lane * 3 + chan];
+        const uint64_t pos = (start & 31) + s_bits[spos];
         auto body = [&](auto& bw) {
             auto put = [&](uint32_t code, uint32_t len) { bw.put(code, len); };
-            put_dc(dc - pred, s_dc[chan ? 1 : 0], put);
+            put_dc(dc - pred, s_dc[chroma ? 1 : 0], put);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if ((uint32_t)i * 32u < aclen) {
@@ -1074,7 +1233,7 @@ __global__ void __launch_bounds__(192)
     }
     if (!use_lds) return;
     __syncthreads();
-    for (uint32_t i = tid; i < nw; i += 192) {
+    for (uint32_t i = tid; i < nw; i += NT) {
         uint32_t v = __builtin_bswap32(s_words[i]);
         bool shared = (i == 0 && (start & 31)) || (i == nw - 1 && (end & 31) && !last_tile);
         if (shared) {
@@ -1091,7 +1250,7 @@ __global__ void __launch_bounds__(192)
 // Number of persistent WAVES (4 per workgroup).  Full groups of 8 workgroups whenever the
 // work allows, so that the XCD-aware tile mapping applies.
 uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves) {
-    uint32_t total = g.tiles * 3 * n_frames;
+    uint32_t total = g.tiles * g.passes * n_frames;
     uint32_t wgs = (total + kEncWaves - 1) / kEncWaves;
     uint32_t max_wgs = max_waves / kEncWaves ? max_waves / kEncWaves : 1;
     if (wgs > max_wgs) wgs = max_wgs;
@@ -1101,21 +1260,25 @@ uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves) {
 hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,
                                 bool probe, uint32_t grid_waves, hipStream_t s) {
     uint32_t grid = screen_grid(g, n_frames, grid_waves) / kEncWaves;
-    const bool stdm = (g.flags & 2u) != 0;  // MI355_F_STANDARD
-    if (probe && stdm)
-        hipLaunchKernelGGL((k_screen_encode<true, true>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
-    else if (probe)
-        hipLaunchKernelGGL((k_screen_encode<true, false>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
-    else if (stdm)
-        hipLaunchKernelGGL((k_screen_encode<false, true>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
-    else
-        hipLaunchKernelGGL((k_screen_encode<false, false>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp);
+    const int mode = is420(g) ? 2 : ((g.flags & 2u) ? 1 : 0);  // MI355_F_STANDARD, 4:2:0
+#define MI355_LAUNCH_ENC(PR, MD) \
+    hipLaunchKernelGGL((k_screen_encode<PR, MD>), dim3(grid), dim3(256), 0, s, g, n_frames, rgb, sp)
+    if (probe) {
+        if (mode == 2) MI355_LAUNCH_ENC(true, 2);
+        else if (mode == 1) MI355_LAUNCH_ENC(true, 1);
+        else MI355_LAUNCH_ENC(true, 0);
+    } else {
+        if (mode == 2) MI355_LAUNCH_ENC(false, 2);
+        else if (mode == 1) MI355_LAUNCH_ENC(false, 1);
+        else MI355_LAUNCH_ENC(false, 0);
+    }
+#undef MI355_LAUNCH_ENC
     return hipGetLastError();
 }
 hipError_t launch_fixup(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp, bool probe,
                         hipStream_t s) {
     // one lane per (tile, channel) head when the batch is small, a few per lane when it is large
-    const uint64_t heads = (uint64_t)n_frames * g.tiles * 3;
+    const uint64_t heads = (uint64_t)n_frames * g.tiles * g.passes;
     uint32_t grid_waves = (uint32_t)((heads + 63) / 64 < 2048 ? (heads + 63) / 64 : 2048);
     if (grid_waves < 32) grid_waves = 32;
     if (probe)
@@ -1135,8 +1298,12 @@ hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, con
                         uint8_t* out, uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,
                         hipStream_t s) {
     if (lds_words_limit > kEmitLdsWords) lds_words_limit = kEmitLdsWords;
-    hipLaunchKernelGGL(k_merge, dim3(g.tiles, n_frames), dim3(192), 0, s, g, meta, arena, lut,
-                       tile_off, out, out_stride, status, lds_words_limit);
+    if (is420(g))
+        hipLaunchKernelGGL(k_merge<true>, dim3(g.tiles, n_frames), dim3(384), 0, s, g, meta, arena, lut,
+                           tile_off, out, out_stride, status, lds_words_limit);
+    else
+        hipLaunchKernelGGL(k_merge<false>, dim3(g.tiles, n_frames), dim3(192), 0, s, g, meta, arena, lut,
+                           tile_off, out, out_stride, status, lds_words_limit);
     return hipGetLastError();
 }
 

@@ -285,7 +285,10 @@ int upload_afrag(mi355_jpeg_ctx* c) {
 
 int make_geom(uint32_t W, uint32_t H, uint32_t flags, const void* base, Geom* g) {
     if (W == 0 || H == 0 || W > 65535u || H > 65535u) return MI355_E_ARG;
-    uint32_t W8 = (W + 7) / 8 * 8, H8 = (H + 7) / 8 * 8;
+    if ((flags & MI355_F_420) && !(flags & MI355_F_STANDARD)) return MI355_E_ARG;  // real 4:2:0 MCUs: standard mode only
+    const bool s420 = (flags & MI355_F_420) != 0;
+    const uint32_t A = s420 ? 16 : 8;  // MCU edge
+    uint32_t W8 = (W + A - 1) / A * A, H8 = (H + A - 1) / A * A;
     // the reference mirrors with `oldWidth - diff` in size_t (utils.cpp:215,226):
     // a pad wider than the image underflows there (UB) -> refused here
     if (W8 - W > W || H8 - H > H) return MI355_E_ARG;
@@ -294,7 +297,9 @@ int make_geom(uint32_t W, uint32_t H, uint32_t flags, const void* base, Geom* g)
     g->W8 = W8;
     g->H8 = H8;
     g->nbx = W8 / 8;
-    g->N = (W8 / 8) * (H8 / 8);
+    g->nmx = W8 / 16;
+    g->passes = s420 ? 6 : 3;
+    g->N = (W8 / A) * (H8 / A);  // 8x8 blocks per channel, or 16x16 MCUs in 4:2:0
     g->tiles = (g->N + 63) / 64;
     g->flags = flags;
     g->frame_stride = (uint64_t)W * H * 3;
@@ -317,7 +322,7 @@ constexpr size_t kMaxEventSets = 1u << 16;
 // workspace of the screened pipeline; arena_words: capacity for the AC blobs
 int ensure_screen_workspace(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, size_t arena_words) {
     int e;
-    size_t slots = (size_t)g.tiles * 3 * 64 * n_frames;
+    size_t slots = (size_t)g.tiles * g.passes * 64 * n_frames;
     if ((e = ensure(c->d_meta, c->meta_cap, slots))) return e;
     if ((e = ensure(c->d_fixlist, c->fixlist_cap, slots))) return e;
     if ((e = ensure(c->d_arena, c->arena_cap, arena_words))) return e;
@@ -357,7 +362,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.arena_words = (uint32_t)(arena_words > 0xFFFFFFFFull ? 0xFFFFFFFFull : arena_words);
     sp.counters = c->d_counters;
     sp.fixlist = c->d_fixlist;
-    sp.fixcap = (uint32_t)((size_t)g.tiles * 3 * 64 * n_frames);
+    sp.fixcap = (uint32_t)((size_t)g.tiles * g.passes * 64 * n_frames);
     sp.status = c->d_status;
     sp.tile_bits = c->d_tile_bits;
     sp.coefs = coefs;
@@ -436,7 +441,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     // AC blobs are word aligned per unit: at most total_bits/32 + one word per unit
     // AC strings are word aligned per unit (<= bits/32 + 1 words); strings longer than the LDS
     // slot (24 words) get a full 54-word run, i.e. at most 54/24 of their own size
-    ArenaPlan plan = plan_arena(c, g, n_frames, (size_t)n_frames * (out_stride / 4 * 9 / 4 + (size_t)g.N * 3 + 64));
+    ArenaPlan plan = plan_arena(c, g, n_frames, (size_t)n_frames * (out_stride / 4 * 9 / 4 + unit_count(g) + 64));
     if (plan.total_words > 0xFFFFFFFFull) return MI355_E_ARG;  // 32-bit word offsets: split the batch
     int e;
     if ((e = ensure_screen_workspace(c, g, n_frames, plan.total_words))) return e;
@@ -457,7 +462,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
 
 // Screened transform only (stage probes): coefficients into the tiled workspace layout.
 int run_screened_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, uint8_t* d_samples, hipStream_t s) {
-    ArenaPlan plan = plan_arena(c, g, 1, (size_t)g.N * 3 * 54);
+    ArenaPlan plan = plan_arena(c, g, 1, unit_count(g) * 54);
     if (plan.total_words > 0xFFFFFFFFull) return MI355_E_ARG;
     int e;
     if ((e = ensure_screen_workspace(c, g, 1, plan.total_words))) return e;
@@ -725,6 +730,7 @@ int mi355_jpeg_probe_samples(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, 
     if ((e = ensure(c->d_out, c->out_cap, ob))) return e;
     HIP_TRY(hipMemcpy(c->d_in, rgb, g.frame_stride, hipMemcpyHostToDevice));
     if ((flags & MI355_F_STANDARD) && c->transform_mode != 2) return MI355_E_ARG;
+    if (flags & MI355_F_420) return MI355_E_ARG;  // no full-resolution chroma planes exist in 4:2:0
     if (c->transform_mode == 2) {
         // the screened pipeline has its own (integer-exact) sample stage: probe that one
         if ((e = ensure_workspace(c, g, 1))) return e;
@@ -756,7 +762,7 @@ int mi355_jpeg_probe_coefficients(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_
     Geom g;
     int e = transform_to_workspace(c, rgb, W, H, flags, &g);
     if (e) return e;
-    size_t ob = (size_t)g.N * 3 * 64 * sizeof(int16_t);
+    size_t ob = unit_count(g) * 64 * sizeof(int16_t);
     if ((e = ensure(c->d_out, c->out_cap, ob))) return e;
     HIP_TRY(launch_coefs_to_rows(g, c->d_coefs, (int16_t*)c->d_out, nullptr));
     HIP_TRY(hipMemcpy(out, c->d_out, ob, hipMemcpyDeviceToHost));
@@ -786,6 +792,7 @@ int mi355_jpeg_entropy_only(mi355_jpeg_ctx* c, const int16_t* zigzag, uint32_t n
     Geom g;
     memset(&g, 0, sizeof g);
     g.N = n_blocks;
+    g.passes = 3;
     g.tiles = (n_blocks + 63) / 64;
     HIP_TRY(hipSetDevice(c->device));
     int e;
@@ -874,7 +881,7 @@ int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, ui
         for (int k = 0; k < 64; ++k) w.b(q[zz[k]] > 255 ? 255 : q[zz[k]]);
     }
     w.w(0xFFC0), w.w(17), w.b(8), w.w(H), w.w(W), w.b(3);
-    w.b(1), w.b(0x11), w.b(0);
+    w.b(1), w.b((flags & MI355_F_420) ? 0x22 : 0x11), w.b(0);
     w.b(2), w.b(0x11), w.b(1);
     w.b(3), w.b(0x11), w.b(1);
     const mi355_huff_table* ht = (flags & MI355_F_STANDARD) ? c->huff_std : c->huff;

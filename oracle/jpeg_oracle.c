@@ -515,17 +515,30 @@ static int std_unit(const int32_t zz[64], int32_t dc_diff, int chroma, struct or
     return nbits;
 }
 
+/* one 8x8 block of level-shifted samples -> quantised zig-zag row, in exact integers */
+static void std_block(const int32_t p[64], const uint32_t *q, const uint8_t zz[64], const int64_t *dct,
+                      int32_t *row) {
+    for (int R = 0; R < 64; ++R) {
+        int64_t Y = 0;
+        for (int s = 0; s < 64; ++s) Y += dct[R * 64 + s] * p[s];
+        int64_t D = (int64_t)q[zz[R]] << 39, a = Y < 0 ? -Y : Y;
+        int64_t n = (2 * a + D) / (2 * D);
+        row[R] = (int32_t)(Y < 0 ? -n : n);
+    }
+}
+
 int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
-                   const uint32_t qchrom[64], const int64_t *dct, int keep, orc_result *out) {
-    if (!rgb || !out || !dct || W == 0 || H == 0) return ORC_E_ARG;
+                   const uint32_t qchrom[64], const int64_t *dct, int subsample, int keep, orc_result *out) {
+    if (!rgb || !out || !dct || W == 0 || H == 0 || subsample < 0 || subsample > 1) return ORC_E_ARG;
     memset(out, 0, sizeof *out);
-    size_t W8, H8;
-    orc_padded_size(W, H, &W8, &H8);
-    if (W8 - W > W || H8 - H > H) return ORC_E_ARG;
-    const size_t N = W8 * H8 / 64, bw = W8 / 8;
-    out->W8 = W8, out->H8 = H8, out->n_blocks = N;
-    uint8_t *img = (uint8_t *)malloc(W * H * 3), *pad = (uint8_t *)malloc(W8 * H8 * 3);
-    int32_t *zig = (int32_t *)malloc(N * 3 * 64 * sizeof(int32_t));
+    const size_t A = subsample ? 16 : 8; /* MCU edge in pixels */
+    const size_t Wp = (W + A - 1) / A * A, Hp = (H + A - 1) / A * A;
+    if (Wp - W > W || Hp - H > H) return ORC_E_ARG;
+    const size_t M = (Wp / A) * (Hp / A);            /* MCUs */
+    const size_t units = subsample ? 6 * M : 3 * M;  /* 8x8 blocks in the scan */
+    out->W8 = Wp, out->H8 = Hp, out->n_blocks = M;
+    uint8_t *img = (uint8_t *)malloc(W * H * 3), *pad = (uint8_t *)malloc(Wp * Hp * 3);
+    int32_t *zig = (int32_t *)malloc(units * 64 * sizeof(int32_t));
     for (size_t i = 0; i < W * H; ++i) {
         long r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
         long y = (299 * r + 587 * g + 114 * b + 500) / 1000;
@@ -535,34 +548,57 @@ int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[6
         img[3 * i + 1] = (uint8_t)(cb > 255 ? 255 : cb);
         img[3 * i + 2] = (uint8_t)(cr > 255 ? 255 : cr);
     }
-    orc_pad(img, W, H, pad, W8, H8);
+    orc_pad(img, W, H, pad, Wp, Hp);
     free(img);
     uint8_t zz[64];
     orc_zigzag_order(zz);
-    for (size_t by = 0; by < H8 / 8; ++by)
-        for (size_t bx = 0; bx < bw; ++bx)
-            for (int c = 0; c < 3; ++c) {
+    /* Row order of `zig`.  4:4:4: chan*M + block (like the strict path).  4:2:0: the luma blocks in
+     * scan order (4*mcu + k, k = 2*(row in MCU) + (column in MCU)), then Cb (4M + mcu), then Cr (5M + mcu). */
+    if (!subsample) {
+        const size_t bw = Wp / 8;
+        for (size_t by = 0; by < Hp / 8; ++by)
+            for (size_t bx = 0; bx < bw; ++bx)
+                for (int c = 0; c < 3; ++c) {
+                    int32_t p[64];
+                    for (int s = 0; s < 64; ++s)
+                        p[s] = (int32_t)pad[3 * ((by * 8 + s / 8) * Wp + bx * 8 + s % 8) + c] - 128;
+                    std_block(p, c == 0 ? qlum : qchrom, zz, dct, zig + ((size_t)c * M + by * bw + bx) * 64);
+                }
+    } else {
+        const size_t mw = Wp / 16;
+        for (size_t my = 0; my < Hp / 16; ++my)
+            for (size_t mx = 0; mx < mw; ++mx) {
+                const size_t mcu = my * mw + mx;
                 int32_t p[64];
-                for (int s = 0; s < 64; ++s)
-                    p[s] = (int32_t)pad[3 * ((by * 8 + s / 8) * W8 + bx * 8 + s % 8) + c] - 128;
-                int32_t *row = zig + ((size_t)c * N + by * bw + bx) * 64;
-                const uint32_t *q = c == 0 ? qlum : qchrom;
-                for (int R = 0; R < 64; ++R) {
-                    int64_t Y = 0;
-                    for (int s = 0; s < 64; ++s) Y += dct[R * 64 + s] * p[s];
-                    int64_t D = (int64_t)q[zz[R]] << 39, a = Y < 0 ? -Y : Y;
-                    int64_t n = (2 * a + D) / (2 * D);
-                    row[R] = (int32_t)(Y < 0 ? -n : n);
+                for (int k = 0; k < 4; ++k) {
+                    const size_t x0 = mx * 16 + (k & 1) * 8, y0 = my * 16 + (k >> 1) * 8;
+                    for (int s = 0; s < 64; ++s) p[s] = (int32_t)pad[3 * ((y0 + s / 8) * Wp + x0 + s % 8)] - 128;
+                    std_block(p, qlum, zz, dct, zig + (4 * mcu + k) * 64);
+                }
+                for (int c = 1; c < 3; ++c) {
+                    /* 2x2 mean of the converted samples, rounded to nearest (ties up) */
+                    for (int s = 0; s < 64; ++s) {
+                        const size_t x = mx * 16 + 2 * (s % 8), y = my * 16 + 2 * (s / 8);
+                        const int sum = pad[3 * (y * Wp + x) + c] + pad[3 * (y * Wp + x + 1) + c] +
+                                        pad[3 * ((y + 1) * Wp + x) + c] + pad[3 * ((y + 1) * Wp + x + 1) + c];
+                        p[s] = ((sum + 2) >> 2) - 128;
+                    }
+                    std_block(p, qchrom, zz, dct, zig + ((size_t)(3 + c) * M + mcu) * 64);
                 }
             }
+    }
     free(pad);
-    if (keep & ORC_KEEP_UNIT_BITS) out->unit_bits = (uint32_t *)malloc(N * 3 * sizeof(uint32_t));
+    if (keep & ORC_KEEP_UNIT_BITS) out->unit_bits = (uint32_t *)malloc(units * sizeof(uint32_t));
     struct orc_bitsink sink = {0, 0, 0};
     int32_t pred[3] = {0, 0, 0};
     int err = 0;
-    for (size_t i = 0; i < N && !err; ++i)
-        for (int c = 0; c < 3; ++c) {
-            const int32_t *r = zig + (i + N * (size_t)c) * 64;
+    size_t u = 0; /* unit index in scan order */
+    const int per_mcu = subsample ? 6 : 3;
+    for (size_t i = 0; i < M && !err; ++i)
+        for (int k = 0; k < per_mcu; ++k, ++u) {
+            const int c = subsample ? (k < 4 ? 0 : k - 3) : k;
+            const int32_t *r = subsample ? (k < 4 ? zig + (4 * i + k) * 64 : zig + ((size_t)(3 + c) * M + i) * 64)
+                                         : zig + (i + M * (size_t)c) * 64;
             int32_t diff = r[0] - pred[c];
             pred[c] = r[0];
             int n = std_unit(r, diff, c != 0, &sink);
@@ -570,7 +606,7 @@ int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[6
                 err = n;
                 break;
             }
-            if (out->unit_bits) out->unit_bits[3 * i + c] = (uint32_t)n;
+            if (out->unit_bits) out->unit_bits[u] = (uint32_t)n;
         }
     if (err) {
         free(sink.buf), free(zig);
@@ -624,6 +660,12 @@ static void dht(wr *w, int cls_id, const uint8_t bits[16], const uint8_t *val, i
 
 long orc_jfif_frame(const uint8_t *bits, uint64_t n_bits, size_t W, size_t H,
                     const uint32_t qlum[64], const uint32_t qchrom[64], uint8_t *out, size_t cap) {
+    return orc_jfif_frame_s(bits, n_bits, W, H, qlum, qchrom, 0, out, cap);
+}
+
+/* subsample 1: luma sampling factors 2x2 (4:2:0 MCUs), else 1x1 */
+long orc_jfif_frame_s(const uint8_t *bits, uint64_t n_bits, size_t W, size_t H, const uint32_t qlum[64],
+                      const uint32_t qchrom[64], int subsample, uint8_t *out, size_t cap) {
     wr w = {out, 0, cap, 0};
     uint8_t zz[64];
     orc_zigzag_order(zz);
@@ -637,7 +679,7 @@ long orc_jfif_frame(const uint8_t *bits, uint64_t n_bits, size_t W, size_t H,
         for (int k = 0; k < 64; ++k) w8(&w, q[zz[k]] > 255 ? 255 : q[zz[k]]);
     }
     w16(&w, 0xFFC0), w16(&w, 17), w8(&w, 8), w16(&w, (unsigned)H), w16(&w, (unsigned)W), w8(&w, 3);
-    w8(&w, 1), w8(&w, 0x11), w8(&w, 0);
+    w8(&w, 1), w8(&w, subsample ? 0x22 : 0x11), w8(&w, 0);
     w8(&w, 2), w8(&w, 0x11), w8(&w, 1);
     w8(&w, 3), w8(&w, 0x11), w8(&w, 1);
     dht(&w, 0x00, BITS_DC_L, VAL_DC, 12);

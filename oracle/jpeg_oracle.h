@@ -109,9 +109,15 @@ int orc_entropy(const int32_t *zigzag, size_t n_blocks, uint8_t **bits, size_t *
  *            (tests/golden/std_dct_q39.i64, tools/gen_screen_tables.py);
  *   entropy  Annex-K tables without the reference's seven 17-bit typos, EOB
  *            omitted when coefficient 63 is non-zero.
- * keep: ORC_KEEP_ZIGZAG / ORC_KEEP_UNIT_BITS. */
+ * keep: ORC_KEEP_ZIGZAG / ORC_KEEP_UNIT_BITS.
+ *   subsample 0: 4:4:4, one Y, Cb, Cr block per 8x8 MCU; zigzag rows chan*M + block.
+ *   subsample 1: 4:2:0, 16x16 MCUs (Y00 Y01 Y10 Y11 Cb Cr), image mirror-padded to multiples of 16,
+ *            chroma = (sum of the 2x2 converted samples + 2) >> 2; zigzag rows: luma 4*mcu + k,
+ *            then Cb at 4M + mcu, Cr at 5M + mcu; n_blocks = M (MCUs); unit_bits in scan order. */
 int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
-                   const uint32_t qchrom[64], const int64_t *dct, int keep, orc_result *out);
+                   const uint32_t qchrom[64], const int64_t *dct, int subsample, int keep, orc_result *out);
+long orc_jfif_frame_s(const uint8_t *bits, uint64_t n_bits, size_t W, size_t H, const uint32_t qlum[64],
+                      const uint32_t qchrom[64], int subsample, uint8_t *out, size_t cap);
 
 /* Pinned synthetic input of SURVEY §8d: LCG s <- s*1664525+1013904223,
  * byte = s>>24, seed = 1+frame. */

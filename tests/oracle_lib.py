@@ -58,7 +58,10 @@ def oracle():
         L.orc_lcg_fill.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
         L.orc_std_encode.restype = C.c_int
         L.orc_std_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_int, C.POINTER(OrcResult)]
+                                     C.c_int, C.c_int, C.POINTER(OrcResult)]
+        L.orc_jfif_frame_s.restype = C.c_long
+        L.orc_jfif_frame_s.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_jfif_frame.restype = C.c_long
         L.orc_jfif_frame.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_size_t]
@@ -207,8 +210,8 @@ def std_dct_table():
     return np.fromfile(os.path.join(ROOT, "tests", "golden", "std_dct_q39.i64"), "<i8").reshape(64, 64)
 
 
-def oracle_std_encode(rgb, qlum, qchrom, keep=0):
-    """Standard (decodable, 4:4:4) mode of the test oracle."""
+def oracle_std_encode(rgb, qlum, qchrom, keep=0, subsample=0):
+    """Standard (decodable) mode of the test oracle; subsample 0 = 4:4:4, 1 = 4:2:0."""
     rgb = np.ascontiguousarray(rgb, np.uint8)
     H, W, _ = rgb.shape
     qlum = np.ascontiguousarray(qlum, np.uint32)
@@ -216,15 +219,15 @@ def oracle_std_encode(rgb, qlum, qchrom, keep=0):
     dct = np.ascontiguousarray(std_dct_table(), np.int64)
     res = OrcResult()
     rc = oracle().orc_std_encode(rgb.ctypes.data, W, H, qlum.ctypes.data, qchrom.ctypes.data, dct.ctypes.data,
-                                 keep, C.byref(res))
+                                 subsample, keep, C.byref(res))
     if rc != 0:
         raise RuntimeError("orc_std_encode failed: %d" % rc)
     out = Encoded()
     out.W8, out.H8, out.n_blocks, out.n_bits = res.W8, res.H8, res.n_blocks, res.n_bits
     out.bits = np.ctypeslib.as_array(res.bits, (res.bits_bytes,)).copy()
-    N = res.n_blocks
-    out.zigzag = np.ctypeslib.as_array(res.zigzag, (3 * N, 64)).copy() if res.zigzag else None
-    out.unit_bits = np.ctypeslib.as_array(res.unit_bits, (3 * N,)).copy() if res.unit_bits else None
+    units = (6 if subsample else 3) * res.n_blocks
+    out.zigzag = np.ctypeslib.as_array(res.zigzag, (units, 64)).copy() if res.zigzag else None
+    out.unit_bits = np.ctypeslib.as_array(res.unit_bits, (units,)).copy() if res.unit_bits else None
     oracle().orc_result_free(C.byref(res))
     return out
 
@@ -270,13 +273,13 @@ def unpack_bits(packed, n_bits):
     return np.unpackbits(np.asarray(packed, np.uint8))[:n_bits]
 
 
-def jfif_frame(bits, n_bits, W, H, qlum, qchrom):
+def jfif_frame(bits, n_bits, W, H, qlum, qchrom, subsample=0):
     bits = np.ascontiguousarray(bits, np.uint8)
     cap = 2 * bits.size + 2048
     out = np.empty(cap, np.uint8)
     qlum = np.ascontiguousarray(qlum, np.uint32)
     qchrom = np.ascontiguousarray(qchrom, np.uint32)
-    n = oracle().orc_jfif_frame(bits.ctypes.data, n_bits, W, H, qlum.ctypes.data,
-                                qchrom.ctypes.data, out.ctypes.data, cap)
+    n = oracle().orc_jfif_frame_s(bits.ctypes.data, n_bits, W, H, qlum.ctypes.data,
+                                  qchrom.ctypes.data, subsample, out.ctypes.data, cap)
     assert n > 0
     return out[:n].tobytes()

@@ -38,9 +38,9 @@ def pil_decode(data):
     return np.asarray(PIL.open(io.BytesIO(data)).convert("RGB"))
 
 
-def pil_encode(rgb, ql, qc):
+def pil_encode(rgb, ql, qc, subsample=0):
     buf = io.BytesIO()  # Pillow takes the tables in natural order and writes them zig-zagged
-    PIL.fromarray(rgb).save(buf, "JPEG", subsampling=0,
+    PIL.fromarray(rgb).save(buf, "JPEG", subsampling=2 if subsample else 0,
                             qtables=[[int(v) for v in ql.reshape(64)], [int(v) for v in qc.reshape(64)]])
     return buf.getvalue()
 
@@ -73,6 +73,26 @@ def test_oracle_standard_files_decode_like_an_independent_encoder(quality):
     # colour conversion round differently; fruit.ppm is close to noise, so that is the worst case) and
     # both are equally far from the source
     assert psnr(ours, theirs) > 30.0
+    assert abs(psnr(ours, rgb) - psnr(theirs, rgb)) < 0.1
+
+
+@pytest.mark.parametrize("kind,quality", [("fruit", 50), ("fruit", 90), ("smooth", 50), ("smooth", 92)])
+def test_oracle_420_files_decode_like_an_independent_encoder(kind, quality):
+    """4:2:0: 16x16 MCUs, sampling factors 2x2 / 1x1 / 1x1 -- decoded by libjpeg, compared with
+    Pillow's own 4:2:0 encoder on the same tables (odd sizes: mirror padding to multiples of 16)."""
+    rgb = ol.read_ppm(os.path.join(GOLD, "fruit.ppm")) if kind == "fruit" else smooth_frame(333, 201, 4)
+    ql, qc = ol.quant_tables(quality)
+    o = ol.oracle_std_encode(rgb, ql, qc, KEEP, subsample=1)
+    H, W, _ = rgb.shape
+    M = ((W + 15) // 16) * ((H + 15) // 16)
+    assert o.n_blocks == M and o.zigzag.shape == (6 * M, 64) and o.n_bits == int(o.unit_bits.sum())
+    f = ol.jfif_frame(o.bits, o.n_bits, W, H, ql, qc, 1)
+    sof = f.index(b"\xff\xc0")
+    assert f[sof + 10:sof + 19] == bytes([1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1])
+    ours = pil_decode(f)
+    theirs = pil_decode(pil_encode(rgb, ql, qc, 1))
+    assert ours.shape == rgb.shape
+    assert psnr(ours, theirs) > (35.0 if kind == "fruit" else 44.0)
     assert abs(psnr(ours, rgb) - psnr(theirs, rgb)) < 0.1
 
 
@@ -185,3 +205,48 @@ def test_gpu_standard_batch_and_strict_interleaved(jpeg, enc):
         bits, nb = enc.encode_scan(frames, jpeg.F_CDS)
         for f in range(3):
             assert nb[f] == want_strict[f].n_bits and np.array_equal(bits[f], want_strict[f].bits)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,q,kind", [(253, 254, 50, "fruit"), (640, 368, 50, "lcg"), (100, 37, 90, "lcg"),
+                                        (1920, 1080, 75, "smooth"), (16, 16, 100, "lcg"), (8, 9, 60, "lcg"),
+                                        (333, 65, 25, "smooth"), (1024, 1024, 95, "lcg"), (1040, 16, 80, "lcg"),
+                                        (3840, 2160, 50, "lcg")])
+def test_gpu_420_equals_checker(jpeg, enc, W, H, q, kind):
+    """Real 4:2:0 (MI355_F_STANDARD | MI355_F_420): scan bits and coefficients equal the checker's,
+    incl. sizes that need mirror padding to 16, a last tile with empty luma quarter-tiles, one-MCU images."""
+    rgb = (ol.read_ppm(os.path.join(GOLD, "fruit.ppm")) if kind == "fruit"
+           else ol.lcg_frame(W, H, 7) if kind == "lcg" else smooth_frame(W, H, 2))
+    ql, qc = ol.quant_tables(q)
+    enc.set_quant(ql, qc)
+    flags = jpeg.F_STANDARD | jpeg.F_420
+    o = ol.oracle_std_encode(rgb, ql, qc, KEEP, subsample=1)
+    cf = enc.probe_coefficients(rgb, flags)
+    assert cf.shape == o.zigzag.shape
+    assert np.array_equal(cf.astype(np.int32), o.zigzag)
+    bits, nb = enc.encode_scan(rgb, flags)
+    assert nb[0] == o.n_bits
+    assert np.array_equal(bits[0], o.bits)
+    enc.set_quality(50)
+
+
+@pytest.mark.gpu
+def test_gpu_420_jfif_decodes_and_batches(jpeg, enc):
+    ql, qc = ol.quant_tables(85)
+    enc.set_quant(ql, qc)
+    flags = jpeg.F_STANDARD | jpeg.F_420
+    rgb = smooth_frame(650, 490, 5)
+    got = enc.encode_jfif(rgb, flags)
+    o = ol.oracle_std_encode(rgb, ql, qc, subsample=1)
+    assert got == ol.jfif_frame(o.bits, o.n_bits, 650, 490, ql, qc, 1)
+    dec = pil_decode(got)
+    assert dec.shape == rgb.shape and psnr(dec, rgb) > 33.0
+    assert psnr(dec, pil_decode(pil_encode(rgb, ql, qc, 1))) > 44.0
+    frames = np.stack([ol.lcg_frame(272, 144, s) for s in (1, 2, 3, 4, 5)])
+    bits, nb = enc.encode_scan(frames, flags)
+    for f in range(5):
+        w = ol.oracle_std_encode(frames[f], ql, qc, subsample=1)
+        assert nb[f] == w.n_bits and np.array_equal(bits[f], w.bits)
+    with pytest.raises(jpeg.JpegError):  # 4:2:0 MCUs exist in standard mode only
+        enc.encode_scan(rgb, jpeg.F_420)
+    enc.set_quality(50)

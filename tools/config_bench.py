@@ -58,3 +58,5 @@ if __name__ == "__main__":
     if "std" in which:
         run("standard mode 4K q50", 3840, 2160, 1, 50, jpeg.F_STANDARD, 8 << 20, 50)
         run("standard mode 4K q90", 3840, 2160, 1, 90, jpeg.F_STANDARD, 16 << 20, 20)
+        run("standard 4:2:0 4K q50", 3840, 2160, 1, 50, jpeg.F_STANDARD | jpeg.F_420, 8 << 20, 50)
+        run("standard 4:2:0 4K q50 x16 frames per call", 3840, 2160, 16, 50, jpeg.F_STANDARD | jpeg.F_420, 8 << 20, 10)
