@@ -115,6 +115,34 @@ __device__ __forceinline__ void load_raw_rowpair(const uint8_t* __restrict__ f, 
     }
 }
 
+// The same conversion on a pixel fetched as rg = R | G << 16 (one v_perm_b32 on the raw dwords) and b:
+// the R and G terms are one v_dot2 (16-bit lanes), so four instructions form the weighted sum
+// instead of six.  The chroma numerators are divisible by 32 for every input (all six constants
+// and 128e6 are), so floor(x / 1e6) == floor((x / 32) / 31250) with constants that fit 16 bits:
+// 168736/32 = 5273, 331264/32 = 10352, 500000/32 = 15625, 418688/32 = 13084, 81312/32 = 2541.
+// Same results as csc_int for all 2^24 inputs (the exhaustive colour conversion tests run this one).
+template <bool STD>
+__device__ __forceinline__ uint32_t csc_packed(int chan, uint32_t rg, uint32_t b) {
+    typedef short v2s __attribute__((ext_vector_type(2)));
+    const v2s RG = __builtin_bit_cast(v2s, rg);
+    if (chan == 0) {
+        const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, v2s{299, 587}, (int)(114u * b), false);  // <= 255000
+        if constexpr (STD) return (s + 500u) / 1000u;
+        uint32_t y = s / 1000u;
+        if (s - y * 1000u == 0u) y = csc1(rg & 0xffffu, rg >> 16, b, 0.299, 0.587, 0.114, 0.0);
+        return y;
+    } else {
+        const int kb = chan == 1 ? 15625 : -2541;
+        const v2s K = chan == 1 ? v2s{-5273, -10352} : v2s{15625, -13084};
+        const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, K, 4000000 + kb * (int)b, false);  // (128e6 + ...) / 32 > 0
+        if constexpr (STD) {
+            const uint32_t v = (s + 15625u) / 31250u;
+            return v > 255u ? 255u : v;
+        }
+        return s / 31250u;
+    }
+}
+
 // 16 samples of channel CHAN from the raw row pair, packed 4 per dword in sample order
 // (y*8+x), as unsigned bytes; chroma averaging over the 2x2 quads of the row pair.
 template <int CHAN, bool STD>
@@ -124,13 +152,14 @@ __device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool av
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
-            uint32_t c[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                int byte = 3 * x + k;
-                c[k] = (w[r * 6 + (byte >> 2)] >> (8 * (byte & 3))) & 255u;
-            }
-            val[r][x] = csc_int<STD>(CHAN, c[0], c[1], c[2]);
+            // pixel x = bytes 3x, 3x+1, 3x+2 of the row: R and G through a byte permute of the two
+            // dwords around them (selector 0..3 = low dword, 4..7 = high dword, 0x0c = zero)
+            constexpr uint32_t kZ = 0x0cu;
+            const int o = 3 * x, i = o >> 2, k = o & 3;
+            const uint32_t lo = w[r * 6 + i], hi = w[r * 6 + (i < 5 ? i + 1 : i)];
+            const uint32_t rg = __builtin_amdgcn_perm(hi, lo, (uint32_t)k | (kZ << 8) | ((uint32_t)(k + 1) << 16) | (kZ << 24));
+            const uint32_t b = (w[r * 6 + ((o + 2) >> 2)] >> (8 * ((o + 2) & 3))) & 255u;
+            val[r][x] = csc_packed<STD>(CHAN, rg, b);
         }
     if (avg) {
 #pragma unroll
@@ -191,13 +220,12 @@ __device__ __forceinline__ void convert_chroma420_row(const uint32_t (&w)[24], u
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                uint32_t c[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    int byte = 3 * (2 * x + h) + k;
-                    c[k] = (w[r * 12 + (byte >> 2)] >> (8 * (byte & 3))) & 255u;
-                }
-                sum += csc_int<true>(CHAN, c[0], c[1], c[2]);
+                constexpr uint32_t kZ = 0x0cu;
+                const int o = 3 * (2 * x + h), i = o >> 2, k = o & 3;
+                const uint32_t lo = w[r * 12 + i], hi = w[r * 12 + (i < 11 ? i + 1 : i)];
+                const uint32_t rg = __builtin_amdgcn_perm(hi, lo, (uint32_t)k | (kZ << 8) | ((uint32_t)(k + 1) << 16) | (kZ << 24));
+                const uint32_t b = (w[r * 12 + ((o + 2) >> 2)] >> (8 * ((o + 2) & 3))) & 255u;
+                sum += csc_packed<true>(CHAN, rg, b);
             }
         m[x] = sum >> 2;
     }

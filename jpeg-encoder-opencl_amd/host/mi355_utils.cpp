@@ -22,6 +22,9 @@ namespace {
 
 mi355_jpeg_ctx* g_ctx = nullptr;
 int g_device = 0, g_quality = 50;
+unsigned g_mode = 0;  // MI355_F_STANDARD [| MI355_F_420], or 0 = strict
+
+unsigned path_flags(bool cds) { return g_mode ? g_mode : (cds ? MI355_F_CDS : 0u); }
 
 int fail(int rc) {
     std::cout << "mi355-jpeg: " << mi355_jpeg_strerror(rc) << std::endl;
@@ -190,6 +193,8 @@ int mi355_select(int device, int quality) {
     return ensure_ctx();
 }
 
+void mi355_set_mode(unsigned mode_flags) { g_mode = mode_flags & (MI355_F_STANDARD | MI355_F_420); }
+
 int JpegEncoderDevice(ppm_t img, GPUTelemetry* tel, std::string* scanData, bool cds) {
     if (ensure_ctx()) return 1;
     std::vector<uint8_t> scan(mi355_jpeg_scan_bound((uint32_t)img.width, (uint32_t)img.height));
@@ -197,7 +202,7 @@ int JpegEncoderDevice(ppm_t img, GPUTelemetry* tel, std::string* scanData, bool 
     mi355_jpeg_set_profiling(g_ctx, 1);
     auto t0 = std::chrono::steady_clock::now();
     int rc = mi355_jpeg_encode_scan(g_ctx, (const uint8_t*)img.data, (uint32_t)img.width, (uint32_t)img.height, 1,
-                                    cds ? MI355_F_CDS : 0u, scan.data(), scan.size(), &nbits);
+                                    path_flags(cds), scan.data(), scan.size(), &nbits);
     auto t1 = std::chrono::steady_clock::now();
     if (rc) return fail(rc);
     if (tel) {
@@ -258,7 +263,7 @@ int writeJpegFile(const char* path, ppm_t img, bool cds) {
     size_t cap = 2 * mi355_jpeg_scan_bound((uint32_t)img.width, (uint32_t)img.height) + 4096, len = 0;
     std::vector<uint8_t> buf(cap);
     int rc = mi355_jpeg_encode_jfif(g_ctx, (const uint8_t*)img.data, (uint32_t)img.width, (uint32_t)img.height,
-                                    cds ? MI355_F_CDS : 0u, buf.data(), cap, &len);
+                                    path_flags(cds), buf.data(), cap, &len);
     if (rc) return fail(rc);
     FILE* fp = fopen(path, "wb");
     if (!fp) {

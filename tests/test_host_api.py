@@ -73,6 +73,32 @@ def test_cli_ppm_to_jpg(tmp_path):
     assert subprocess.call([CLI, "/nonexistent.ppm", out]) == 1
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub", ["420", "444"])
+def test_cli_standard_mode_writes_a_decodable_jpeg(tmp_path, sub):
+    """--mode standard: the file equals the checker's framing of the checker's bits and decodes in
+    Pillow (when importable) to the source picture."""
+    subprocess.check_call(["make", "-s", "-C", PKG, "all", "host"])
+    out = str(tmp_path / "fruit.jpg")
+    subprocess.check_call([CLI, os.path.join(GOLD, "fruit.ppm"), out, "--mode", "standard", "--subsample", sub,
+                           "-q", "90"])
+    rgb = ol.read_ppm(os.path.join(GOLD, "fruit.ppm"))
+    ql, qc = ol.quant_tables(90)
+    ss = 1 if sub == "420" else 0
+    o = ol.oracle_std_encode(rgb, ql, qc, subsample=ss)
+    data = open(out, "rb").read()
+    assert data == ol.jfif_frame(o.bits, o.n_bits, rgb.shape[1], rgb.shape[0], ql, qc, ss)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    dec = np.asarray(Image.open(out).convert("RGB")).astype(np.float64)
+    assert dec.shape == rgb.shape
+    mse = ((dec - rgb) ** 2).mean()
+    assert 10 * np.log10(255.0 ** 2 / mse) > (19.5 if ss else 29.0)  # fruit.ppm is close to noise
+    assert subprocess.call([CLI, os.path.join(GOLD, "fruit.ppm"), out, "--mode", "standard", "--subsample", "ref420"]) == 2
+
+
 def test_ppm_reader_accepts_wellformed_headers(tmp_path):
     """No GPU needed: the host reader takes the reference's strict 3-line form and every other
     well-formed P6/255 header (comments, arbitrary whitespace), and rejects bad input with -1

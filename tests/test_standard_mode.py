@@ -96,6 +96,19 @@ def test_oracle_420_files_decode_like_an_independent_encoder(kind, quality):
     assert abs(psnr(ours, rgb) - psnr(theirs, rgb)) < 0.1
 
 
+def test_chroma_numerators_divide_by_32_for_all_inputs():
+    """The HIP colour conversion forms the chroma numerators divided by 32 (constants that fit the
+    16-bit lanes of v_dot2): floor(x / 1e6) == floor((x / 32) / 31250) and the rounded variants, for
+    all 2^24 inputs -- the algebra behind csc_packed() in jpeg_screen_kernels.hip."""
+    v = np.arange(256, dtype=np.int64)
+    r, g, b = v[:, None, None], v[None, :, None], v[None, None, :]
+    for x, y in ((128000000 + 500000 * b - 168736 * r - 331264 * g, 4000000 + 15625 * b - 5273 * r - 10352 * g),
+                 (128000000 + 500000 * r - 418688 * g - 81312 * b, 4000000 + 15625 * r - 13084 * g - 2541 * b)):
+        assert (x == 32 * y).all() and (y > 0).all() and (y < 2 ** 31).all()
+        assert (x // 1000000 == y // 31250).all()
+        assert ((x + 500000) // 1000000 == (y + 15625) // 31250).all()
+
+
 def test_oracle_standard_coefficients_against_float_dct():
     """Independent arithmetic: scipy's orthonormal fp64 DCT-II of the same samples, divided and
     rounded half away, gives the same integers except within 1e-6 of a rounding tie."""
