@@ -313,7 +313,13 @@ __device__ __forceinline__ int dc_predictor(const uint32_t* __restrict__ coefs_f
 }
 
 
-constexpr uint32_t kEmitLdsWords = 4096;  // 16 KiB = 131072 bits = 682 bits per unit on average
+#ifndef MI355_EMIT_LDS_WORDS
+#define MI355_EMIT_LDS_WORDS 4096
+#endif
+// Bit-assembly window of k_emit / k_merge: 4096 words = 16 KiB = 131072 bits = 682 bits per unit on
+// average (tiles with more bits take the direct-to-memory path).  With its 17,280 B of LDS one merge
+// workgroup fits on a CU next to two workgroups of k_screen_encode (2 x 72,832 B of 160 KiB).
+constexpr uint32_t kEmitLdsWords = MI355_EMIT_LDS_WORDS;
 
 struct BitWriterLds {
     uint32_t* words;  // LDS

@@ -42,9 +42,7 @@ struct ScreenParams {
     uint32_t arena_words;   // = grid * region_words + overflow pool
     uint32_t region_words;  // private region of each persistent wave (bump-allocated without atomics)
     uint32_t overflow_base; // first word of the shared overflow pool (= grid * region_words)
-    uint32_t* counters;     // [0] overflow-pool words used, [1] fix-up list length
-    uint32_t* fixlist;      // unit slot indices to recompute exactly
-    uint32_t fixcap;
+    uint32_t* counters;     // [0] overflow-pool words used
     uint32_t* status;
     uint32_t* tile_bits;    // [frame][tile] bit totals, accumulated with atomics (zero on entry)
     uint32_t* coefs;        // probe output (tiled coefficient layout) or nullptr
@@ -56,8 +54,7 @@ struct ScreenParams {
 uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves);
 hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,
                                 bool probe, uint32_t grid_waves, hipStream_t s);
-hipError_t launch_fixup(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp, bool probe,
-                        hipStream_t s);
+hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams& sp, hipStream_t s);
 hipError_t launch_meta_sizes(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* lut,
                              uint32_t* unit_off, uint32_t* tile_bits, uint32_t* status, hipStream_t s);
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,

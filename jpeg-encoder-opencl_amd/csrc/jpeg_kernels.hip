@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(1024)
                 uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ frame_bits,
                 uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters, uint32_t rearm_tiles) {
     __shared__ uint64_t s_wave[16];
+    __builtin_amdgcn_s_setprio(3);  // short, on the stream's critical path, resident next to encode kernels
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t frame = blockIdx.x;
     uint32_t* tb = tile_bits + (size_t)frame * g.tiles;

@@ -49,28 +49,35 @@ constexpr uint32_t kSlotWordsFull = 54;  // worst case 63*(17+10)+4 = 1705 bits
 // ----------------------------------------------------------------------------
 // STD = standard mode (not a behaviour of the reference): round to nearest
 // instead of truncating, clamp to 255; pure integer arithmetic.
+// (a * m) >> 32 for a, m < 2^24 on the full-rate 24-bit multiplier (v_mul_hi_u32 is quarter rate,
+// and the compiler cannot see the operand ranges behind the dot product).
+__device__ __forceinline__ uint32_t mulhi24(uint32_t a, uint32_t m) {
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(m), "v"(a));
+    return r;
+}
+// s / 1000 for s <= 255500 and s / 31250 for s < 8.1e6 (both checked exhaustively,
+// tests/test_standard_mode.py::test_division_constants)
+__device__ __forceinline__ uint32_t div1000(uint32_t s) { return mulhi24(s, 8589935u) >> 1; }
+__device__ __forceinline__ uint32_t div31250(uint32_t s) { return mulhi24(s, 8796094u) >> 6; }
+
 template <bool STD>
 __device__ __forceinline__ uint32_t csc_int(int chan, uint32_t r, uint32_t g, uint32_t b) {
     if (chan == 0) {
         uint32_t s = 299u * r + 587u * g + 114u * b;  // <= 255000
-        if constexpr (STD) return (s + 500u) / 1000u;
-        uint32_t y = s / 1000u;
-        if (s - y * 1000u == 0u) y = csc1(r, g, b, 0.299, 0.587, 0.114, 0.0);
+        if constexpr (STD) return div1000(s + 500u);
+        uint32_t y = div1000(s);
+        if (s == __umul24(y, 1000u)) y = csc1(r, g, b, 0.299, 0.587, 0.114, 0.0);
         return y;
-    } else if (chan == 1) {
-        uint32_t s = 128000000u + 500000u * b - 168736u * r - 331264u * g;
-        if constexpr (STD) {
-            uint32_t v = (s + 500000u) / 1000000u;
-            return v > 255u ? 255u : v;
-        }
-        return s / 1000000u;
     } else {
-        uint32_t s = 128000000u + 500000u * r - 418688u * g - 81312u * b;
+        // numerators divided by 32 (exact: every constant and 128e6 are multiples of 32)
+        const uint32_t s = chan == 1 ? 4000000u + 15625u * b - 5273u * r - 10352u * g
+                                     : 4000000u + 15625u * r - 13084u * g - 2541u * b;
         if constexpr (STD) {
-            uint32_t v = (s + 500000u) / 1000000u;
+            const uint32_t v = div31250(s + 15625u);
             return v > 255u ? 255u : v;
         }
-        return s / 1000000u;
+        return div31250(s);
     }
 }
 
@@ -126,20 +133,20 @@ __device__ __forceinline__ uint32_t csc_packed(int chan, uint32_t rg, uint32_t b
     typedef short v2s __attribute__((ext_vector_type(2)));
     const v2s RG = __builtin_bit_cast(v2s, rg);
     if (chan == 0) {
-        const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, v2s{299, 587}, (int)(114u * b), false);  // <= 255000
-        if constexpr (STD) return (s + 500u) / 1000u;
-        uint32_t y = s / 1000u;
-        if (s - y * 1000u == 0u) y = csc1(rg & 0xffffu, rg >> 16, b, 0.299, 0.587, 0.114, 0.0);
+        const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, v2s{299, 587}, (int)(114u * b), false);
+        if constexpr (STD) return div1000(s + 500u);  // s <= 255000
+        uint32_t y = div1000(s);
+        if (s == __umul24(y, 1000u)) y = csc1(rg & 0xffffu, rg >> 16, b, 0.299, 0.587, 0.114, 0.0);
         return y;
     } else {
         const int kb = chan == 1 ? 15625 : -2541;
         const v2s K = chan == 1 ? v2s{-5273, -10352} : v2s{15625, -13084};
-        const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, K, 4000000 + kb * (int)b, false);  // (128e6 + ...) / 32 > 0
-        if constexpr (STD) {
-            const uint32_t v = (s + 15625u) / 31250u;
+        const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, K, 4000000 + kb * (int)b, false);  // (128e6 + ...) / 32
+        if constexpr (STD) {  // s < 4000000 + 15625 * 255 < 8e6
+            const uint32_t v = div31250(s + 15625u);
             return v > 255u ? 255u : v;
         }
-        return s / 31250u;
+        return div31250(s);
     }
 }
 
@@ -258,9 +265,10 @@ __device__ __forceinline__ void generic_chroma420(const uint8_t* __restrict__ f,
 // ----------------------------------------------------------------------------
 // (ScreenParams is declared in jpeg_device.h)
 
-struct SlotWriter {  // AC bits of one unit into the lane's LDS slot, layout [word][lane]
-    uint32_t* slot;   // &s_slot[lane]
+struct SlotWriter {  // AC bits of one unit, word w at slot[w * stride]
+    uint32_t* slot;
     uint32_t cap;     // words available
+    uint32_t stride;  // 64: an LDS slot in [word][lane] layout; 1: a run in memory
     uint64_t acc;
     uint32_t n;       // pending bits (< 32)
     uint32_t w;       // words written
@@ -271,14 +279,14 @@ struct SlotWriter {  // AC bits of one unit into the lane's LDS slot, layout [wo
         bits += len;
         if (n >= 32) {
             n -= 32;
-            if (w < cap) slot[w * 64] = (uint32_t)(acc >> n);
+            if (w < cap) slot[w * stride] = (uint32_t)(acc >> n);
             ++w;
             acc &= (1ull << n) - 1;
         }
     }
     __device__ __forceinline__ void flush() {
         if (n) {
-            if (w < cap) slot[w * 64] = (uint32_t)(acc << (32 - n));
+            if (w < cap) slot[w * stride] = (uint32_t)(acc << (32 - n));
             ++w;
         }
     }
@@ -396,7 +404,13 @@ struct WaveArena {
 // (run,size) table.  Bits are packed with 32-bit funnel shifts.  LDS reads are
 // software-pipelined two symbols ahead.  Same bits as walk_ac().
 // ----------------------------------------------------------------------------
-constexpr uint32_t kSlotRows = 24;  // words per unit in the LDS slot; larger strings re-walk into global memory
+// The kernel's LDS is kept at 72,832 B per workgroup (24 slot rows, no fp64 threshold table), so that
+// next to the two resident workgroups of a CU one workgroup of k_merge (17,280 B) or k_fixup still
+// fits: another stream's tail kernels then run under this kernel instead of waiting for it.
+#ifndef MI355_SLOT_ROWS
+#define MI355_SLOT_ROWS 24
+#endif
+constexpr uint32_t kSlotRows = MI355_SLOT_ROWS;  // words per unit in the LDS slot; larger strings re-walk into global memory
 // Symbol table layout [run][value + 32]: the value-0 column (index 32) is all zero (no-op for
 // exhausted lanes, whatever their run); the unused value -32 column carries ZRL and EOB.
 constexpr uint32_t kLut2Zrl = 15 * 64 + 0;
@@ -567,6 +581,63 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
 // MFMA phase lane = (n = lane&15: block within a group of 16, gq = lane>>4: row pair
 // of the block / row group of the accumulator); walk phase lane = block.
 // ----------------------------------------------------------------------------
+// ----------------------------------------------------------------------------
+// The arbiter: the reference's ordered in-place fp64 chain (utils.cpp:314-348) for ONE unit, run by
+// the whole wave for a unit whose screened transform left a coefficient undecided (rare: ~1e-7 of
+// the units).  Lane l owns sample / coefficient l = y*8 + x.  Each of the 64 dependent steps (u
+// outer, v inner) forms its 64 terms (P[y][x]*C[x][u])*C[y][v] in parallel -- multiplying by
+// C[.][0] == 1.0 is the identity, so always multiplying changes nothing -- and lane 0 adds them in
+// the reference's order (y outer, x inner, from 0.0), scales, and publishes P[v][u].  About 25 us
+// per unit, but only a handful of registers and 520 bytes of LDS: no second kernel, no scratch.
+// Rewrites the unit's zig-zag row and non-zero mask in LDS; the caller then carries on as if the
+// screen had produced them.  All lanes must be active.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ void exact_unit_wave(const uint8_t* __restrict__ f, const Geom& g, uint32_t chan, uint32_t bx,
+                                                uint32_t by, const double* __restrict__ qd, double* lds /* 65 doubles */,
+                                                uint32_t* row, uint32_t* mlo, uint32_t* mhi, uint32_t lane) {
+    static constexpr double kCos[8][8] = MI355_COS_TABLE;
+    static constexpr uint8_t kZz[64] = MI355_ZIGZAG_TABLE;  // zig-zag position -> natural index
+    const uint32_t y = lane >> 3, x = lane & 7;
+    const bool avg = (chan != 0) && (g.flags & 1u);
+    const uint32_t smp = sample_generic(f, g, avg, bx * 8 + x, by * 8 + y, csc_k(chan, 0), csc_k(chan, 1), csc_k(chan, 2),
+                                        csc_k(chan, 3));
+    double p = (double)((int)smp - 128);  // quirk Q4
+#pragma unroll 1
+    for (uint32_t u = 0; u < 8; ++u) {
+        const double cxu = kCos[x][u];
+#pragma unroll 1
+        for (uint32_t v = 0; v < 8; ++v) {
+            lds[lane] = (p * cxu) * kCos[y][v];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                double sum = 0.0;
+#pragma unroll 8
+                for (int i = 0; i < 64; ++i) sum += lds[i];
+                sum *= (u == 0 && v == 0) ? kScale00 : ((u == 0 || v == 0) ? kScale0X : kScaleXX);
+                lds[64] = sum;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == v * 8 + u) p = lds[64];  // P[v][u] = s, before the next step (quirk Q5)
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    const int q = (int)__builtin_round(p / qd[(chan ? 64 : 0) + lane]);  // natural index v*8+u == lane (quirk Q6)
+    // natural order -> zig-zag row (int16 pairs) through LDS, then the non-zero mask by ballot
+    int* qn = reinterpret_cast<int*>(lds);
+    __builtin_amdgcn_wave_barrier();
+    qn[lane] = q;
+    __builtin_amdgcn_wave_barrier();
+    const int qz = qn[kZz[lane]];  // coefficient at zig-zag position `lane`
+    const uint64_t nz = __ballot(qz != 0);
+    const int qz_hi = __shfl_down(qz, 1);
+    if ((lane & 1u) == 0) row[lane >> 1] = ((uint32_t)qz & 0xffffu) | ((uint32_t)qz_hi << 16);
+    if (lane == 0) {
+        *mlo = (uint32_t)nz & ~1u;  // bit 0 = "undecided" flag: cleared; coefficient 0 is not walked
+        *mhi = (uint32_t)(nz >> 32);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 constexpr uint32_t kEncWaves = 4;
 
 // Diagnostic build (make STAMPS=1): s_memtime stamps at the phase boundaries of a wave
@@ -594,10 +665,8 @@ __global__ void __launch_bounds__(256, 2)
     constexpr bool STD = MODE != 0, S420 = MODE == 2;
     constexpr uint32_t kPasses = S420 ? 6u : 3u;
     __shared__ uint32_t s_tbuf_all[kEncWaves][64 * 33];            // zig-zag rows, int16 pairs, stride 33 dwords
-    __shared__ uint32_t s_slot_all[kEncWaves][(kSlotRows + 1) * 64];  // AC strings [word][lane] + dump row
+    __shared__ alignas(16) uint32_t s_slot_all[kEncWaves][(kSlotRows + 1) * 64];  // AC strings [word][lane] + dump row
     __shared__ uint32_t s_mask_all[kEncWaves][2][64];              // non-zero masks (lo, hi)
-    __shared__ uint32_t s_flag_all[kEncWaves][64];
-    __shared__ double s_qc[2][64][4];   // {s1, thr1, s2, thr2} per channel type and zig-zag position (fp64 looks)
     __shared__ float s_qf[2][16][8];    // per group of 4 positions: 2^-20/Q x4, first-look thresholds x4
     __shared__ uint32_t s_act[2][256];  // (run,size) AC tables
     __shared__ uint32_t s_lut2[2][1024];  // (run,value) symbol tables
@@ -608,9 +677,7 @@ __global__ void __launch_bounds__(256, 2)
     uint32_t* s_slot = s_slot_all[wv];
     uint32_t* s_mlo = s_mask_all[wv][0];
     uint32_t* s_mhi = s_mask_all[wv][1];
-    uint32_t* s_flag = s_flag_all[wv];
     for (uint32_t i = tid; i < 512; i += 256) {
-        (&s_qc[0][0][0])[i] = sp.qconst[i];
         (&s_act[0][0])[i] = sp.lut[512 + i];
     }
     for (uint32_t i = tid; i < 2048; i += 256) (&s_lut2[0][0])[i] = sp.lut2[i];
@@ -646,7 +713,8 @@ __global__ void __launch_bounds__(256, 2)
 
     WaveArena wa{gwave * sp.region_words, sp.region_words};
 #ifdef MI355_STAMPS
-    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev, wave_t0, wave_t1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wave_t0)::"memory");  // 100 MHz wall clock
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     for (uint32_t p = pstart; p < pairs_total; p += pstep) {
@@ -727,8 +795,14 @@ __global__ void __launch_bounds__(256, 2)
         const bool fast = g.fast_rows && __all(interior);
 
         STAMP(0);
+        // Issue arbitration is oldest-first, and the two workgroups of a CU are dispatched in grid
+        // order: without help the waves of the later-dispatched half of the grid get the leftover
+        // issue slots and finish ~20 % later than the others (measured with in-kernel timestamps:
+        // mean wave end 41.5 vs 49.3 us), leaving the SIMDs half empty at the end.  Raising their
+        // priority outside the (LDS-latency-bound) entropy walk equalises the two halves
+        // (45.9 vs 45.4 us) and shortens the kernel by 8 %.  Speed only.
+        if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(1);
 
-        s_flag[lane] = 0;
         s_mlo[lane] = 0;
         s_mhi[lane] = 0;
         __builtin_amdgcn_wave_barrier();
@@ -843,7 +917,9 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         if (a1[r]) {
-                            const double* qc = &s_qc[ct][16 * mt + 4 * gq + r][0];
+                            // {s1, thr1, s2, thr2} of this position: read from memory, the second look is rare
+                            // and 4 KiB of LDS are worth more as room for another stream's tail kernels
+                            const double* qc = sp.qconst + ((size_t)ct * 64 + 16 * mt + 4 * gq + r) * 4;
                             const double y1 = (double)hi[r] * 65536.0 + (double)mid[r];  // exact
                             const double y2 = y1 * 256.0 + (double)acc0[r];              // exact
                             if constexpr (STD) {
@@ -873,9 +949,9 @@ __global__ void __launch_bounds__(256, 2)
                 if (mt < 2) nzlo |= nib << (16 * mt);
                 else nzhi |= nib << (16 * (mt - 2));
             }
-            atomicOr(&s_mlo[16 * j + n], nzlo << (4 * gq));
+            atomicOr(&s_mlo[16 * j + n], (nzlo << (4 * gq)) & ~1u);
             atomicOr(&s_mhi[16 * j + n], nzhi << (4 * gq));
-            if (amb) s_flag[16 * j + n] = 1;
+            if (amb) atomicOr(&s_mlo[16 * j + n], 1u);  // bit 0 (coefficient 0 is never walked) = "undecided unit"
             STAMP(6);
         }
         {
@@ -897,10 +973,22 @@ __global__ void __launch_bounds__(256, 2)
         __builtin_amdgcn_wave_barrier();
         STAMP(1);
 
+        __builtin_amdgcn_s_setprio(0);
         // ---- walk phase: lane = block
         const uint32_t b = luma420 ? tile * 64 + 16 * chan + (lane >> 2) : tile * 64 + lane;  // block, or MCU in 4:2:0
         const bool active = b < g.N;
-        bool flagged = s_flag[lane] != 0;
+        if constexpr (!STD) {
+            // Units with a coefficient the screen could not decide: the exact chain is the arbiter.
+            const bool undecided = active && (s_mlo[lane] & 1u) != 0;
+            uint64_t todo = __ballot(undecided);
+            while (todo) {  // wave-uniform: one unit at a time, the whole wave on it
+                const uint32_t ul = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t ub = tile * 64 + ul, uby = ub / g.nbx, ubx = ub - uby * g.nbx;
+                exact_unit_wave(f, g, chan, ubx, uby, sp.qd, reinterpret_cast<double*>(s_slot), &s_tbuf[ul * 33], &s_mlo[ul],
+                                &s_mhi[ul], lane);
+            }
+        }
         const i16a* row16 = reinterpret_cast<const i16a*>(&s_tbuf[lane * 33]);
         const uint64_t mask = ((uint64_t)s_mhi[lane] << 32 | s_mlo[lane]) & ~1ull;
         const int dc = (int)row16[0];
@@ -918,22 +1006,20 @@ __global__ void __launch_bounds__(256, 2)
         uint32_t nw = pkr.words();
         STAMP(2);
         const bool oversize = nw > kSlotRows;
-        if (!active) flagged = false;
-        if (!ok && active && !flagged) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY (decided coefficients only)
-        if (!active || flagged) nw = 0;
+        if (!ok && active) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
+        if (!active) nw = 0;
 
         // Total bits of the unit = DC symbol + AC string.  The DC difference needs the previous
         // block of the same channel: the neighbouring lane.  Lane 0's predecessor is the last block
         // of the previous tile, which another wave owns: its DC symbol is left out here and added
-        // by k_fixup from the DCs in `meta` (every DC there is exact).  Tile sums are
-        // accumulated with one atomic per wave (units left to k_fixup add themselves there).
+        // by k_dc_heads from the DCs in `meta`.  Tile sums are accumulated with one atomic per wave.
         {
             const int pred = __shfl_up(dc, 1);
             uint32_t ubits = aclen;
             auto count = [&](uint32_t, uint32_t len) { ubits += len; };
             const bool dc_ok = lane == 0 || put_dc(dc - pred, s_dc[ct], count);
             if (!dc_ok && active) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
-            if (!active || flagged) ubits = 0;
+            if (!active) ubits = 0;
             ubits = wave_sum(ubits);
             if (lane == 0 && ubits) atomicAdd(&sp.tile_bits[(size_t)frame * g.tiles + tile], ubits);
         }
@@ -962,107 +1048,35 @@ __global__ void __launch_bounds__(256, 2)
             }
         }
         sp.meta[us_base + lane] = make_uint2(off, active ? ((aclen << 16) | ((uint32_t)dc & 0xffffu)) : 0u);
-        if (flagged) {
-            uint32_t k = atomicAdd(sp.counters + 1, 1u);
-            if (k < sp.fixcap) sp.fixlist[k] = (uint32_t)(us_base + lane);
-        }
         __builtin_amdgcn_wave_barrier();
         STAMP(4);
     }
 #ifdef MI355_STAMPS
-    if (sp.stamps && lane == 0)
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wave_t1)::"memory");
+    if (sp.stamps && lane == 0) {
         for (int i = 0; i < 8; ++i) sp.stamps[(size_t)gwave * 8 + i] = stamp_sum[i];
+        sp.stamps[(size_t)(2048 + gwave) * 8] = wave_t0;  // start / end of the wave, 10 ns ticks
+        sp.stamps[(size_t)(2048 + gwave) * 8 + 1] = wave_t1;
+    }
 #endif
 }
 
 // ----------------------------------------------------------------------------
-// k_fixup: the exact ordered fp64 chain for listed units (lane = list entry).
+// k_dc_heads: DC symbol of the first unit of every (tile, pass).  Its predecessor is the last
+// block of the previous tile (or luma quarter-tile), encoded by another wave of k_screen_encode,
+// which therefore left the symbol out of the tile sum.  Every DC in `meta` is exact already
+// (fix-ups rewrite the same value).  Light on purpose (few registers, 128 B of LDS): it runs every
+// frame next to another stream's k_screen_encode.
 // ----------------------------------------------------------------------------
-template <bool PROBE>
 __global__ void __launch_bounds__(64)
-    k_fixup(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
-    __shared__ uint32_t s_slot[kSlotWordsFull * 64];
-    __shared__ uint32_t s_act[2][256];
-    __shared__ uint32_t s_smp[16 * 64];
+    k_dc_heads(Geom g, uint32_t n_frames, ScreenParams sp) {
     __shared__ uint32_t s_dcf[2][16];
+    // short kernel on its stream's critical path, usually resident next to another stream's
+    // k_screen_encode: do not let it starve behind those (older) waves
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x;
-    for (uint32_t i = lane; i < 512; i += 64) (&s_act[0][0])[i] = sp.lut[512 + i];
     if (lane < 32) s_dcf[lane >> 4][lane & 15] = sp.lut[(lane >> 4) * 256 + (lane & 15)];
     __syncthreads();
-    uint32_t count = sp.counters[1];
-    if (count > sp.fixcap) count = sp.fixcap;
-    for (uint32_t base = blockIdx.x * 64; base < count; base += gridDim.x * 64) {
-        const bool valid = base + lane < count;
-        const uint32_t us = sp.fixlist[valid ? base + lane : base];
-        const uint32_t ul = us & 63, wt = us >> 6;
-        const uint32_t chan = wt % 3, ft = wt / 3;
-        const uint32_t frame = ft / g.tiles, tile = ft - frame * g.tiles;
-        const uint32_t b = tile * 64 + ul;
-        const uint32_t by = b / g.nbx, bx = b - by * g.nbx;
-        const uint8_t* f = rgb + (size_t)frame * g.frame_stride;
-        const bool avg = (chan != 0) && (g.flags & 1u);
-        const double k0 = csc_k(chan, 0), k1 = csc_k(chan, 1), k2 = csc_k(chan, 2), k3 = csc_k(chan, 3);
-#pragma unroll 1
-        for (int i = 0; i < 16; ++i) {
-            uint32_t v = 0;
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) {
-                int s = i * 4 + j;
-                v |= sample_generic(f, g, avg, bx * 8 + (s & 7), by * 8 + (s >> 3), k0, k1, k2, k3) << (8 * j);
-            }
-            s_smp[i * 64 + lane] = v;
-        }
-        double P[64];
-#pragma unroll
-        for (int s = 0; s < 64; ++s)
-            P[s] = (double)((int)((s_smp[(s >> 2) * 64 + lane] >> (8 * (s & 3))) & 255u) - 128);
-        chain<1>(P);
-        const double* q = sp.qd + (chan ? 64 : 0);
-        int qi[64];
-#pragma unroll
-        for (int i = 0; i < 64; ++i) qi[i] = (int)__builtin_round(P[i] / q[i]);
-        uint32_t c[32];
-#pragma unroll
-        for (int p = 0; p < 32; ++p)
-            c[p] = ((uint32_t)qi[zigzag_nat(2 * p)] & 0xffffu) | ((uint32_t)qi[zigzag_nat(2 * p + 1)] << 16);
-        if constexpr (PROBE) {
-            if (valid) {
-                uint32_t* dst = sp.coefs + (size_t)wt * 2048 + ul;
-#pragma unroll
-                for (int p = 0; p < 32; ++p) dst[p * 64] = c[p];
-            }
-        }
-        SlotWriter sw{&s_slot[lane], kSlotWordsFull, 0, 0, 0, 0};
-        auto put = [&](uint32_t code, uint32_t len) { sw.put(code, len); };
-        bool ok = walk_ac(c, s_act[chan ? 1 : 0], put);
-        const uint32_t aclen = sw.bits;
-        sw.flush();
-        if (valid) {
-            if (!ok) atomicOr(sp.status, 1u);
-            const uint32_t nw = sw.w;
-            const uint32_t off = sp.overflow_base + (nw ? atomicAdd(sp.counters, nw) : 0u);
-            if ((uint64_t)off + nw > sp.arena_words) {
-                atomicOr(sp.status, 2u);
-            } else {
-                for (uint32_t w = 0; w < nw; ++w) sp.arena[off + w] = s_slot[w * 64 + lane];
-            }
-            const int dc = (int)(int16_t)(c[0] & 0xffffu);
-            sp.meta[us] = make_uint2(off, (aclen << 16) | ((uint32_t)dc & 0xffffu));
-            // this unit's share of the tile sum (k_screen_encode left it out); every DC in meta is exact.
-            // The DC symbol of a tile's first unit is added by the loop at the end of this kernel.
-            uint32_t ubits = aclen;
-            if (ul > 0) {
-                const int pred = meta_dc(sp.meta[us - 1].y);
-                auto count = [&](uint32_t, uint32_t len) { ubits += len; };
-                if (!put_dc(dc - pred, s_dcf[chan ? 1 : 0], count)) atomicOr(sp.status, 1u);
-            }
-            atomicAdd(&sp.tile_bits[(size_t)frame * g.tiles + tile], ubits);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    // DC symbol of each tile's first unit, per channel: its predecessor is the last block of the
-    // previous tile, encoded by another wave of k_screen_encode, which therefore left the symbol
-    // out of the tile sum.  Every DC in `meta` is exact already (fix-ups rewrite the same value).
     const uint32_t P = g.passes, heads = n_frames * g.tiles * P;
     for (uint32_t p = blockIdx.x * 64 + lane; p < heads; p += gridDim.x * 64) {
         const uint32_t ft = p / P, c = p - ft * P, tile = ft % g.tiles;
@@ -1152,6 +1166,7 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
             uint8_t* __restrict__ out, uint64_t out_stride, const uint32_t* __restrict__ status,
             uint32_t lds_words_limit) {
     constexpr uint32_t NT = S420 ? 384 : 192, UPB = S420 ? 6 : 3;  // threads, units per scan step (block / MCU)
+    __builtin_amdgcn_s_setprio(3);  // see k_dc_heads
     __shared__ uint32_t s_dc[2][16];
     __shared__ uint32_t s_bits[NT];
     __shared__ uint32_t s_words[kEmitLdsWords];
@@ -1303,16 +1318,11 @@ hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t*
 #undef MI355_LAUNCH_ENC
     return hipGetLastError();
 }
-hipError_t launch_fixup(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp, bool probe,
-                        hipStream_t s) {
-    // one lane per (tile, channel) head when the batch is small, a few per lane when it is large
+hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams& sp, hipStream_t s) {
+    // one lane per (tile, pass) head when the batch is small, a few per lane when it is large
     const uint64_t heads = (uint64_t)n_frames * g.tiles * g.passes;
-    uint32_t grid_waves = (uint32_t)((heads + 63) / 64 < 2048 ? (heads + 63) / 64 : 2048);
-    if (grid_waves < 32) grid_waves = 32;
-    if (probe)
-        hipLaunchKernelGGL((k_fixup<true>), dim3(grid_waves), dim3(64), 0, s, g, n_frames, rgb, sp);
-    else
-        hipLaunchKernelGGL((k_fixup<false>), dim3(grid_waves), dim3(64), 0, s, g, n_frames, rgb, sp);
+    const uint32_t head_waves = (uint32_t)((heads + 63) / 64 < 4096 ? (heads + 63) / 64 : 4096);
+    hipLaunchKernelGGL(k_dc_heads, dim3(head_waves), dim3(64), 0, s, g, n_frames, sp);
     return hipGetLastError();
 }
 hipError_t launch_meta_sizes(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* lut,

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -145,8 +146,6 @@ struct mi355_jpeg_ctx {
     size_t meta_cap = 0;
     uint32_t* d_arena = nullptr;
     size_t arena_cap = 0;           // words
-    uint32_t* d_fixlist = nullptr;
-    size_t fixlist_cap = 0;
     double tau_scale = 1.0;         // debug: widen the accept margins to force fix-ups
     uint32_t screen_waves = 2048;   // persistent single-wave workgroups of k_screen_encode
     int transform_mode = 2;         // 0 exact fp64 chain (unrolled), 1 exact (looped), 2 screened MFMA + exact fix-up
@@ -324,7 +323,6 @@ int ensure_screen_workspace(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames,
     int e;
     size_t slots = (size_t)g.tiles * g.passes * 64 * n_frames;
     if ((e = ensure(c->d_meta, c->meta_cap, slots))) return e;
-    if ((e = ensure(c->d_fixlist, c->fixlist_cap, slots))) return e;
     if ((e = ensure(c->d_arena, c->arena_cap, arena_words))) return e;
     return MI355_OK;
 }
@@ -361,8 +359,6 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.arena = c->d_arena;
     sp.arena_words = (uint32_t)(arena_words > 0xFFFFFFFFull ? 0xFFFFFFFFull : arena_words);
     sp.counters = c->d_counters;
-    sp.fixlist = c->d_fixlist;
-    sp.fixcap = (uint32_t)((size_t)g.tiles * g.passes * 64 * n_frames);
     sp.status = c->d_status;
     sp.tile_bits = c->d_tile_bits;
     sp.coefs = coefs;
@@ -371,7 +367,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
 #ifdef MI355_STAMPS
     {   // diagnostic build: one lazily allocated buffer, dumped by mi355_jpeg_sync
         static unsigned long long* d_st = nullptr;
-        if (!d_st) (void)hipMalloc((void**)&d_st, 8192 * 8 * sizeof(unsigned long long));
+        if (!d_st) (void)hipMalloc((void**)&d_st, 8192 * 8 * sizeof(unsigned long long));  // [0,2048): phase sums, [2048,4096): start/end
         sp.stamps = d_st;
         c->d_stamps = d_st;
     }
@@ -449,7 +445,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     record(c, 0, s);
     HIP_TRY(launch_screen_encode(g, n_frames, d_rgb, sp, false, c->screen_waves, s));
     record(c, 1, s);
-    HIP_TRY(launch_fixup(g, n_frames, d_rgb, sp, false, s));
+    HIP_TRY(launch_dc_heads(g, n_frames, sp, s));
     record(c, 2, s);  // slot [1,2] = exact fix-up (tile sums are accumulated by the encode kernel itself)
     HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
                              c->d_status, c->d_counters, true, s));
@@ -471,7 +467,7 @@ int run_screened_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, u
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(uint32_t), s));
     HIP_TRY(hipMemsetAsync(c->d_tile_bits, 0, (size_t)g.tiles * sizeof(uint32_t), s));
     HIP_TRY(launch_screen_encode(g, 1, d_rgb, sp, true, c->screen_waves, s));
-    HIP_TRY(launch_fixup(g, 1, d_rgb, sp, true, s));
+    HIP_TRY(launch_dc_heads(g, 1, sp, s));
     // leave the accumulators re-armed for the next encode call
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(uint32_t), s));
     HIP_TRY(hipMemsetAsync(c->d_tile_bits, 0, (size_t)g.tiles * sizeof(uint32_t), s));
@@ -558,7 +554,7 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
                     c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
-                    c->d_counters, c->d_meta,     c->d_arena,  c->d_fixlist, c->d_lut2,     c->d_qconst_f,
+                    c->d_counters, c->d_meta,     c->d_arena,  c->d_lut2,     c->d_qconst_f,
                     c->d_stuff_counts, c->d_stuff_offs, c->d_qzz};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -673,13 +669,58 @@ int mi355_jpeg_sync(mi355_jpeg_ctx* c, void* stream) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
 #ifdef MI355_STAMPS
     if (c->d_stamps && getenv("MI355_JPEG_DUMP_STAMPS")) {
-        std::vector<unsigned long long> h(2048 * 8);
+        std::vector<unsigned long long> h(4096 * 8);
         (void)hipMemcpy(h.data(), c->d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
         double sum[8] = {0};
         for (int w = 0; w < 2048; ++w)
             for (int i = 0; i < 8; ++i) sum[i] += (double)h[(size_t)w * 8 + i];
         fprintf(stderr, "[stamps] cycles per wave: setup %.0f | samples %.0f | mfma+quantise %.0f | dc0+barrier %.0f | walk %.0f | dc/sizes %.0f | arena+meta %.0f | loop %.0f\n",
                 sum[0] / 2048, sum[5] / 2048, sum[6] / 2048, sum[1] / 2048, sum[2] / 2048, sum[3] / 2048, sum[4] / 2048, sum[7] / 2048);
+        // wave start / end distribution (10 ns ticks of s_memrealtime) relative to the first start
+        std::vector<double> t0s, t1s;
+        unsigned long long first = ~0ull;
+        for (int w = 0; w < 2048; ++w) first = h[(size_t)(2048 + w) * 8] < first ? h[(size_t)(2048 + w) * 8] : first;
+        for (int w = 0; w < 2048; ++w) {
+            t0s.push_back((double)(h[(size_t)(2048 + w) * 8] - first) * 0.01);
+            t1s.push_back((double)(h[(size_t)(2048 + w) * 8 + 1] - first) * 0.01);
+        }
+        {   // mean wave end per XCD (workgroup id % 8) and per wave slot of the workgroup
+            double ex[8] = {0}, ew[4] = {0}, dur[8] = {0};
+            for (int w = 0; w < 2048; ++w) {
+                ex[(w / 4) % 8] += t1s[(size_t)w] / 256.0;
+                dur[(w / 4) % 8] += (t1s[(size_t)w] - t0s[(size_t)w]) / 256.0;
+                ew[w % 4] += t1s[(size_t)w] / 512.0;
+            }
+            fprintf(stderr, "[stamps] mean end per XCD: %.1f %.1f %.1f %.1f %.1f %.1f %.1f %.1f | per wave slot: %.1f %.1f %.1f %.1f\n",
+                    ex[0], ex[1], ex[2], ex[3], ex[4], ex[5], ex[6], ex[7], ew[0], ew[1], ew[2], ew[3]);
+            {   // by first channel of the wave (local % 3), by workgroup half, by workgroup index within the XCD
+                double e3[3] = {0}, n3[3] = {0}, eh[2] = {0}, nh[2] = {0};
+                int late_by_wgx[64] = {0};
+                for (int w = 0; w < 2048; ++w) {
+                    const int wg = w / 4, local = (wg / 8) * 4 + w % 4;
+                    e3[local % 3] += t1s[(size_t)w], n3[local % 3] += 1;
+                    eh[wg >= 256] += t1s[(size_t)w], nh[wg >= 256] += 1;
+                    if (t1s[(size_t)w] > 46.0) late_by_wgx[wg / 8]++;
+                }
+                fprintf(stderr, "[stamps] mean end by first channel: %.1f %.1f %.1f | by workgroup half: %.1f %.1f\n[stamps] late waves (>46 us) by workgroup index within XCD (of 32 each):",
+                        e3[0] / n3[0], e3[1] / n3[1], e3[2] / n3[2], eh[0] / nh[0], eh[1] / nh[1]);
+                for (int i = 0; i < 64; ++i) fprintf(stderr, " %d", late_by_wgx[i]);
+                fprintf(stderr, "\n");
+            }
+            // histogram of end times, 2 us bins from 28 us
+            int hist[16] = {0};
+            for (double e : t1s) {
+                int b = (int)((e - 28.0) / 2.0);
+                hist[b < 0 ? 0 : b > 15 ? 15 : b]++;
+            }
+            fprintf(stderr, "[stamps] end histogram (2 us bins from 28 us):");
+            for (int b = 0; b < 16; ++b) fprintf(stderr, " %d", hist[b]);
+            fprintf(stderr, "\n");
+        }
+        std::sort(t0s.begin(), t0s.end());
+        std::sort(t1s.begin(), t1s.end());
+        fprintf(stderr, "[stamps] wave start us: p50 %.2f p90 %.2f max %.2f | wave end us: min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
+                t0s[1024], t0s[1843], t0s[2047], t1s[0], t1s[204], t1s[1024], t1s[1843], t1s[2047]);
     }
 #endif
     uint32_t st = 0;

@@ -109,6 +109,15 @@ def test_chroma_numerators_divide_by_32_for_all_inputs():
         assert ((x + 500000) // 1000000 == (y + 15625) // 31250).all()
 
 
+def test_division_constants():
+    """The 24-bit multiply-high divisions of the HIP colour conversion (div1000 / div31250 in
+    jpeg_screen_kernels.hip) are exact over the ranges they are used on."""
+    s = np.arange(0, 256000, dtype=np.uint64)
+    assert (((s * 8589935) >> 33) == s // 1000).all() and 8589935 < 2 ** 24
+    s = np.arange(0, 8100000, dtype=np.uint64)
+    assert (((s * 8796094) >> 38) == s // 31250).all() and 8796094 < 2 ** 24
+
+
 def test_oracle_standard_coefficients_against_float_dct():
     """Independent arithmetic: scipy's orthonormal fp64 DCT-II of the same samples, divided and
     rounded half away, gives the same integers except within 1e-6 of a rounding tie."""
