@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams (one encode context each) the steps alternate over, so that the small "
                          "tail kernels of one frame overlap the block-encode kernel of the next")
+    ap.add_argument("--encode-waves", type=int, default=1024,
+                    help="persistent waves of the block-encode kernel per call when --streams > 1 (0 = fill the device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -187,6 +189,10 @@ def main():
     encs = [jpeg.Encoder(local_rank) for _ in range(S)]
     for e in encs:
         e.set_quality(QUALITY)
+        if S > 1:
+            # several calls in flight: half the device per call (two block-encode kernels resident
+            # side by side, each wave amortises its set-up over twice as many tiles)
+            e.set_encode_waves(args.encode_waves)
     enc = encs[0]
 
     R = max(1, args.ring)
@@ -230,9 +236,11 @@ def main():
     dt = max_over_ranks(dt, dist, distributed, dev)
 
     # Duration of the dominant kernel: HIP events on its launch stream, in a single-stream pass
-    # over the same steps right after the timed region.  (With two streams an event bracket also
-    # contains the time a launch waits for CUs still held by the other stream's kernel, which
-    # rocprofv3's per-kernel duration does not; single-stream brackets agree with rocprofv3.)
+    # over the same steps right after the timed region, one call at a time on the whole device.
+    # (In the timed region several calls share the device -- two block-encode kernels resident side
+    # by side, tail kernels of other frames under them -- so a per-kernel duration there measures the
+    # sharing, not the kernel; `python bench.py --streams 1` under rocprofv3 shows the same number.)
+    enc.set_encode_waves(0)  # one call at a time on the whole device, as rocprofv3 --streams 1 sees it
     enc.set_profiling(2)
     for i in range(min(args.steps, 100)):
         k = i % R
@@ -271,6 +279,7 @@ def main():
                                    "q=50 tables, chroma averaging on, strict (bit-exact) mode, device-resident "
                                    "RGB -> packed scan bits",
                        "frames_per_step": 1, "ring_frames": R, "streams": S,
+                       "encode_waves_per_call": (args.encode_waves or 2048) if S > 1 else 2048,
                        "sharding": "frames across ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,

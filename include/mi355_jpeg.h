@@ -106,6 +106,14 @@ int mi355_jpeg_reference_huffman(int table, mi355_huff_table *t);
 int mi355_jpeg_get_quant(mi355_jpeg_ctx *ctx, uint32_t qlum[64], uint32_t qchrom[64]);
 int mi355_jpeg_get_huffman(mi355_jpeg_ctx *ctx, int table, mi355_huff_table *t);
 
+/* ---- tuning --------------------------------------------------------------
+ * Persistent waves of the block-encode kernel per call: 0 = default (fill the device: lowest
+ * latency for one call at a time), or a multiple of 32 in [32, 8192].  Callers that keep several
+ * encode calls in flight on one device (one context + stream each, like bench.py) do better with
+ * half the device per call (1024 on MI355X): two calls are then resident side by side and each
+ * wave amortises its table set-up over twice as many tiles.  Speed only; results are identical. */
+int mi355_jpeg_set_encode_waves(mi355_jpeg_ctx *ctx, uint32_t waves);
+
 /* ---- geometry helpers (getNearest8x8ImageSize, utils.cpp:184-187) ------ */
 void mi355_jpeg_padded_size(uint32_t W, uint32_t H, uint32_t *W8, uint32_t *H8);
 /* Upper bound in bytes of one frame's packed scan bits (what to size `out` as). */

@@ -51,6 +51,7 @@ ABI_SYMBOLS = [
     "mi355_jpeg_entropy_only", "mi355_jpeg_set_profiling", "mi355_jpeg_last_timings",
     "mi355_jpeg_profile_summary", "mi355_jpeg_synth_lcg_device", "mi355_jpeg_stuff_device", "mi355_jpeg_pool_create", "mi355_jpeg_pool_destroy", "mi355_jpeg_pool_workers",
     "mi355_jpeg_pool_set_quant", "mi355_jpeg_pool_set_quality", "mi355_jpeg_pool_encode",
+    "mi355_jpeg_set_encode_waves",
 ]
 
 _lib = None
@@ -87,6 +88,7 @@ def lib():
         L.mi355_jpeg_set_quant.argtypes = [vp, vp, vp]
         L.mi355_jpeg_set_quality.argtypes = [vp, C.c_int]
         L.mi355_jpeg_set_huffman.argtypes = [vp, C.c_int, C.POINTER(HuffTable)]
+        L.mi355_jpeg_set_encode_waves.argtypes = [vp, u32]
         L.mi355_jpeg_get_quant.argtypes = [vp, vp, vp]
         L.mi355_jpeg_get_huffman.argtypes = [vp, C.c_int, C.POINTER(HuffTable)]
         L.mi355_jpeg_reference_huffman.argtypes = [C.c_int, C.POINTER(HuffTable)]
@@ -167,6 +169,10 @@ class Encoder:
 
     def set_quality(self, quality):
         _check(lib().mi355_jpeg_set_quality(self._h, quality))
+
+    def set_encode_waves(self, waves):
+        """Persistent waves of the block-encode kernel per call (0 = default: fill the device)."""
+        _check(lib().mi355_jpeg_set_encode_waves(self._h, int(waves)))
 
     def get_quant(self):
         ql, qc = np.zeros(64, np.uint32), np.zeros(64, np.uint32)

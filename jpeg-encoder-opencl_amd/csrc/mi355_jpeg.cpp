@@ -606,6 +606,12 @@ int mi355_jpeg_set_huffman(mi355_jpeg_ctx* c, int table, const mi355_huff_table*
     return upload_tables(c);
 }
 
+int mi355_jpeg_set_encode_waves(mi355_jpeg_ctx* c, uint32_t waves) {
+    if (!c || (waves != 0 && (waves < 32 || waves > 8192 || (waves & 31)))) return MI355_E_ARG;
+    c->screen_waves = waves ? waves : 2048;
+    return MI355_OK;
+}
+
 int mi355_jpeg_reference_huffman(int table, mi355_huff_table* t) {
     if (!t || table < 0 || table > 3) return MI355_E_ARG;
     reference_huffman(table, t);
