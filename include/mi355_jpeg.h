@@ -71,8 +71,9 @@ typedef struct mi355_huff_table {
  * the call's stream).  Mirrors the role of CPUTelemetry (utils.hpp:65-75). */
 typedef struct mi355_jpeg_timings {
     /* default (screened) pipeline / exact pipeline (MI355_JPEG_TRANSFORM_MODE=0,1): */
-    float transform_ms; /* k_screen_encode: CSC..zig-zag + per-unit RLE/Huffman strings / k_transform (utils.cpp:92-558) */
-    float size_ms;      /* k_fixup: exact fp64 chain for undecided units / k_unit_sizes (utils.cpp:572-653) */
+    float transform_ms; /* k_screen_encode: CSC..zig-zag + per-unit RLE/Huffman strings (incl. the rare exact
+                           fp64 recomputation) / k_transform (utils.cpp:92-558) */
+    float size_ms;      /* k_dc_heads: DC symbols at tile heads / k_unit_sizes (utils.cpp:572-653) */
     float scan_ms;      /* k_tile_scan: exclusive prefix sum of tile bit counts */
     float emit_ms;      /* k_merge / k_emit: final bit string (HuffmanEncoder, utils.cpp:656-698) */
     float total_ms;

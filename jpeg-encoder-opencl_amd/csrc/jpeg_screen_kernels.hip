@@ -11,8 +11,8 @@
 // |c_k/Q_k - z_k| <= tau_k with z_k = (Lt p)_k / Q_k.  The reference's quantiser
 // round(fl(c/Q)) equals round-half-away of the exact quotient, so
 // whenever z_k is farther than tau_k from every half-integer the quantised value
-// is decided.  Units with an undecided coefficient are recomputed by k_fixup with
-// the exact ordered fp64 chain -- that chain remains the arbiter.  Coefficient 0 is
+// is decided.  Units with an undecided coefficient are recomputed (inside the same kernel,
+// exact_unit_wave) with the exact ordered fp64 chain -- that chain remains the arbiter.  Coefficient 0 is
 // always exact: row 0 of L is SCALE_00 * ones, so c_0 = fl(sum(p) * SCALE_00) is
 // formed directly.
 //
@@ -20,8 +20,8 @@
 //   k_screen_encode  RGB -> per-unit {DC, AC bit string (word-aligned blob in an arena)}
 //                    samples (integer-exact CSC), MFMA map, quantise+verify, LDS transpose to
 //                    zig-zag rows, per-unit RLE/Huffman walk into an LDS slot, blob store
-//   k_fixup          exact fp64 chain for the (rare) undecided / oversized units
-//   k_meta_sizes     DC code lengths + AC lengths -> tile-local offsets, tile sums
+//                    (+ the exact fp64 chain for the rare undecided units)
+//   k_dc_heads       DC symbol of each tile's first unit per pass -> tile sums
 //   k_tile_scan      (jpeg_kernels.hip) 64-bit scan of tile sums
 //   k_merge          DC symbols + AC blobs -> final bit string (LDS window per tile)
 #include "jpeg_devfn.h"
@@ -405,7 +405,7 @@ struct WaveArena {
 // software-pipelined two symbols ahead.  Same bits as walk_ac().
 // ----------------------------------------------------------------------------
 // The kernel's LDS is kept at 72,832 B per workgroup (24 slot rows, no fp64 threshold table), so that
-// next to the two resident workgroups of a CU one workgroup of k_merge (17,280 B) or k_fixup still
+// next to the two resident workgroups of a CU one workgroup of k_merge (17,280 B) or k_dc_heads still
 // fits: another stream's tail kernels then run under this kernel instead of waiting for it.
 #ifndef MI355_SLOT_ROWS
 #define MI355_SLOT_ROWS 24

@@ -430,8 +430,8 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
     return MI355_OK;
 }
 
-// Screened pipeline: k_screen_encode -> k_fixup -> k_tile_scan -> k_merge.
-// Event slots: [0,1] fused block encode (transform_ms), [1,2] exact fix-up (size_ms), [2,3] scan, [3,4] merge (emit_ms).
+// Screened pipeline: k_screen_encode -> k_dc_heads -> k_tile_scan -> k_merge.
+// Event slots: [0,1] fused block encode (transform_ms), [1,2] DC heads (size_ms), [2,3] scan, [3,4] merge (emit_ms).
 int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t* d_rgb, uint8_t* d_out,
                  size_t out_stride, uint64_t* d_bits, hipStream_t s) {
     // AC blobs are word aligned per unit: at most total_bits/32 + one word per unit
@@ -446,7 +446,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     HIP_TRY(launch_screen_encode(g, n_frames, d_rgb, sp, false, c->screen_waves, s));
     record(c, 1, s);
     HIP_TRY(launch_dc_heads(g, n_frames, sp, s));
-    record(c, 2, s);  // slot [1,2] = exact fix-up (tile sums are accumulated by the encode kernel itself)
+    record(c, 2, s);  // slot [1,2] = DC heads (the other tile sums are accumulated by the encode kernel itself)
     HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
                              c->d_status, c->d_counters, true, s));
     record(c, 3, s);

@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
     for (int r = 0; r < repeat; ++r)
         if (JpegEncoderDevice(img, &tel, r == repeat - 1 ? &scan : NULL, cds)) return 1;
     std::cout << "Block encode (CSC..RLE/Huffman strings) Time GPU: " << tel.blockEncodeTime << " us\n"
-              << "Exact fix-up Time GPU: " << tel.fixupTime << " us\n"
+              << "DC heads Time GPU: " << tel.fixupTime << " us\n"
               << "Prefix scan Time GPU: " << tel.scanTime << " us\n"
               << "Bit string emit Time GPU: " << tel.emitTime << " us\n"
               << "Total Time GPU: " << tel.totalTime << " us (wall incl. transfers " << tel.wallTime << " us)\n"

@@ -45,7 +45,7 @@ extern const std::vector<std::vector<std::string>> AC_CHROMA_HUFF_CODES;
 // ---- telemetry (role of CPUTelemetry, utils.hpp:65-75), microseconds ---------------
 struct GPUTelemetry {
     double blockEncodeTime;  // fused CSC .. per-unit RLE/Huffman strings (k_screen_encode)
-    double fixupTime;        // exact fp64 chain for undecided units (k_fixup)
+    double fixupTime;        // DC symbols at tile heads (k_dc_heads; the name dates from a separate fix-up kernel)
     double scanTime;         // prefix sum of tile bit counts
     double emitTime;         // final bit string
     double totalTime;        // device time of the whole path
