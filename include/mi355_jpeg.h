@@ -154,6 +154,13 @@ int mi355_jpeg_sync(mi355_jpeg_ctx *ctx, void *stream);
 int mi355_jpeg_encode_jfif(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, uint32_t H,
                            uint32_t flags, uint8_t *out, size_t cap, size_t *out_len);
 
+/* The same container around a scan that is already in host memory (e.g. one frame of
+ * mi355_jpeg_pool_encode): header, byte-stuffed entropy bytes, EOI.  Host only -- framing is data
+ * format, not the hot path; `flags` must be the flags the scan was encoded with, the context must
+ * hold the same tables.  MI355_E_CAPACITY when cap is too small (*out_len = the size needed). */
+int mi355_jpeg_wrap_jfif(mi355_jpeg_ctx *ctx, const uint8_t *scan, uint64_t n_bits, uint32_t W, uint32_t H,
+                         uint32_t flags, uint8_t *out, size_t cap, size_t *out_len);
+
 /* ---- stage probes (host buffers; one frame) ----------------------------
  * Let every stage be parity-checked like the reference's per-stage dumps. */
 /* Samples entering the transform: after performCSC, performCDS and padding

@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "mi355_jpeg_entropy_only", "mi355_jpeg_set_profiling", "mi355_jpeg_last_timings",
     "mi355_jpeg_profile_summary", "mi355_jpeg_synth_lcg_device", "mi355_jpeg_stuff_device", "mi355_jpeg_pool_create", "mi355_jpeg_pool_destroy", "mi355_jpeg_pool_workers",
     "mi355_jpeg_pool_set_quant", "mi355_jpeg_pool_set_quality", "mi355_jpeg_pool_encode",
-    "mi355_jpeg_set_encode_waves",
+    "mi355_jpeg_set_encode_waves", "mi355_jpeg_wrap_jfif",
 ]
 
 _lib = None
@@ -100,6 +100,7 @@ def lib():
         L.mi355_jpeg_encode_scan_device.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, vp, vp]
         L.mi355_jpeg_sync.argtypes = [vp, vp]
         L.mi355_jpeg_encode_jfif.argtypes = [vp, vp, u32, u32, u32, vp, sz, C.POINTER(sz)]
+        L.mi355_jpeg_wrap_jfif.argtypes = [vp, vp, C.c_uint64, u32, u32, u32, vp, sz, C.POINTER(sz)]
         L.mi355_jpeg_probe_samples.argtypes = [vp, vp, u32, u32, u32, vp]
         L.mi355_jpeg_probe_coefficients.argtypes = [vp, vp, u32, u32, u32, vp]
         L.mi355_jpeg_probe_unit_bits.argtypes = [vp, vp, u32, u32, u32, vp]
@@ -217,6 +218,16 @@ class Encoder:
         n = C.c_size_t()
         _check(lib().mi355_jpeg_encode_jfif(self._h, rgb.ctypes.data, W, H, flags, out.ctypes.data, cap,
                                             C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def wrap_jfif(self, scan, n_bits, W, H, flags=F_DEFAULT):
+        """Container around a host-resident scan (header, stuffed bytes, EOI)."""
+        scan = np.ascontiguousarray(scan, np.uint8)
+        cap = 2 * scan.size + 4096
+        out = np.empty(cap, np.uint8)
+        n = C.c_size_t()
+        _check(lib().mi355_jpeg_wrap_jfif(self._h, scan.ctypes.data, n_bits, W, H, flags, out.ctypes.data, cap,
+                                          C.byref(n)))
         return out[:n.value].tobytes()
 
     # ---- hot path, device buffers (raw pointers, e.g. torch tensor .data_ptr())

@@ -905,19 +905,10 @@ void dht_segment(Writer& w, int cls_id, const mi355_huff_table& t) {
     for (int i = 0; i < 16; ++i) w.b(bits[i]);
     for (uint8_t v : vals) w.b(v);
 }
-}  // namespace
-
-int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
-                           uint8_t* out, size_t cap, size_t* out_len) {
-    if (!c || !rgb || !out || !out_len) return MI355_E_ARG;
-    Geom g;
-    int e = make_geom(W, H, flags, nullptr, &g);
-    if (e) return e;
-    HIP_TRY(hipSetDevice(c->device));
-    // header (host): SOI, APP0, DQT x2, SOF0 (H1V1 x3), DHT x4, SOS
+// header of the build-defined container: SOI, APP0, DQT x2, SOF0, DHT x4, SOS; returns its length
+size_t jfif_header(const mi355_jpeg_ctx* c, uint32_t W, uint32_t H, uint32_t flags, uint8_t* dst, size_t cap) {
     static const uint8_t zz[64] = MI355_ZIGZAG_TABLE;
-    std::vector<uint8_t> hdr(1024);
-    Writer w{hdr.data(), 0, hdr.size()};
+    Writer w{dst, 0, cap};
     w.w(0xFFD8);
     w.w(0xFFE0), w.w(16);
     w.b('J'), w.b('F'), w.b('I'), w.b('F'), w.b(0);
@@ -939,7 +930,36 @@ int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, ui
     w.w(0xFFDA), w.w(12), w.b(3);
     w.b(1), w.b(0x00), w.b(2), w.b(0x11), w.b(3), w.b(0x11);
     w.b(0), w.b(63), w.b(0);
-    const size_t hlen = w.n;
+    return w.n;
+}
+}  // namespace
+
+int mi355_jpeg_wrap_jfif(mi355_jpeg_ctx* c, const uint8_t* scan, uint64_t n_bits, uint32_t W, uint32_t H, uint32_t flags,
+                         uint8_t* out, size_t cap, size_t* out_len) {
+    if (!c || !scan || !out || !out_len || W == 0 || H == 0 || W > 65535u || H > 65535u) return MI355_E_ARG;
+    if ((flags & MI355_F_420) && !(flags & MI355_F_STANDARD)) return MI355_E_ARG;
+    Writer w{out, jfif_header(c, W, H, flags, out, cap), cap};
+    const size_t nb = (size_t)((n_bits + 7) / 8);
+    for (size_t i = 0; i < nb; ++i) {  // entropy bytes: last partial byte padded with 1s, 0xFF -> 0xFF 0x00
+        unsigned b = scan[i];
+        if (i == nb - 1 && (n_bits & 7)) b |= 0xFFu >> (n_bits & 7);
+        w.b(b);
+        if (b == 0xFF) w.b(0);
+    }
+    w.w(0xFFD9);
+    *out_len = w.n;
+    return w.n > cap ? MI355_E_CAPACITY : MI355_OK;
+}
+
+int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
+                           uint8_t* out, size_t cap, size_t* out_len) {
+    if (!c || !rgb || !out || !out_len) return MI355_E_ARG;
+    Geom g;
+    int e = make_geom(W, H, flags, nullptr, &g);
+    if (e) return e;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint8_t> hdr(1024);
+    const size_t hlen = jfif_header(c, W, H, flags, hdr.data(), hdr.size());
     if (hlen + 2 > cap) return MI355_E_CAPACITY;
 
     // scan on the device, stuffed on the device (k_stuff_*), one copy back

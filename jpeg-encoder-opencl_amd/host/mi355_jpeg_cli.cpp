@@ -2,6 +2,11 @@
 //
 //   mi355-jpeg in.ppm out.jpg [-q N] [--mode strict|standard] [--subsample ref420|none|420|444]
 //              [--no-cds] [--device K] [--repeat R] [--bits out.bits]
+//   mi355-jpeg --batch IN_DIR OUT_DIR [-q N] [--mode ...] [--subsample ...]
+//
+// --batch: every *.ppm of IN_DIR -> OUT_DIR/<name>.jpg.  Runs of files of one size are encoded as one
+// batch through mi355_jpeg_pool_encode (frames sharded over all visible GPUs, no collective),
+// framed on the host (mi355_jpeg_wrap_jfif).  Same bytes as the one-file form.
 //
 // --mode strict (default): the reference's arithmetic; --subsample ref420 (default) = its performCDS
 // (2x2 chroma means written back at full resolution), none (= --no-cds) skips it.
@@ -13,24 +18,120 @@
 // report the stage times; the reference writes no output file, this tool writes
 // ../data/fruit.jpg.  Strict mode reproduces the reference's arithmetic, so the file's
 // pixels are not a meaningful picture; its scan bits are the parity artefact.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "mi355_utils.hpp"
 
 static void usage() {
     std::cout << "usage: mi355-jpeg in.ppm out.jpg [-q 1..100] [--mode strict|standard] [--subsample ref420|none|420|444]\n"
                  "                  [--no-cds] [--device K] [--repeat R] [--bits file]\n"
+                 "       mi355-jpeg --batch IN_DIR OUT_DIR [-q ..] [--mode ..] [--subsample ..]   (all visible GPUs)\n"
                  "       (no arguments: ../data/fruit.ppm -> ../data/fruit.jpg, like the reference's fixed paths)\n";
+}
+
+// --batch: directory in, directory out, through the multi-GPU pool
+static int run_batch(const std::string& in_dir, const std::string& out_dir, int quality, unsigned flags) {
+    namespace fs = std::filesystem;
+    std::vector<std::string> files;
+    std::error_code ec;
+    for (const auto& e : fs::directory_iterator(in_dir, ec))
+        if (e.is_regular_file() && e.path().extension() == ".ppm") files.push_back(e.path().string());
+    if (ec || files.empty()) {
+        std::cout << "mi355-jpeg: no .ppm files in " << in_dir << std::endl;
+        return 1;
+    }
+    std::sort(files.begin(), files.end());
+    fs::create_directories(out_dir, ec);
+    mi355_jpeg_pool* pool = nullptr;
+    mi355_jpeg_ctx* ctx = nullptr;  // tables for the framing
+    int rc = mi355_jpeg_pool_create(nullptr, 0, &pool);
+    if (!rc) rc = mi355_jpeg_pool_set_quality(pool, quality);
+    if (!rc) rc = mi355_jpeg_create(0, &ctx);
+    if (!rc) rc = mi355_jpeg_set_quality(ctx, quality);
+    if (rc) {
+        std::cout << "mi355-jpeg: " << mi355_jpeg_strerror(rc) << std::endl;
+        return 1;
+    }
+    std::cout << "Batch: " << files.size() << " files, " << mi355_jpeg_pool_workers(pool) << " GPU worker(s)" << std::endl;
+    const size_t kMaxBatchBytes = (size_t)2 << 30;  // host memory per batch of frames
+    double px_total = 0, enc_seconds = 0;
+    const auto t_all = std::chrono::steady_clock::now();
+    size_t i = 0;
+    int status = 0;
+    while (i < files.size() && !status) {
+        // a run of consecutive files of one size
+        std::vector<uint8_t> frames;
+        std::vector<std::string> names;
+        size_t W = 0, H = 0;
+        while (i < files.size()) {
+            ppm_t img;
+            if (readPPMImage(files[i].c_str(), &img.width, &img.height, &img.data) == -1) {
+                std::cout << "  skipped (not a P6/255 file): " << files[i] << std::endl;
+                ++i;
+                continue;
+            }
+            if (names.empty()) W = img.width, H = img.height;
+            if (img.width != W || img.height != H || frames.size() + W * H * 3 > kMaxBatchBytes) {
+                free(img.data);
+                break;  // starts the next run
+            }
+            frames.insert(frames.end(), (uint8_t*)img.data, (uint8_t*)img.data + W * H * 3);
+            names.push_back(files[i]);
+            free(img.data);
+            ++i;
+        }
+        if (names.empty()) continue;
+        const uint32_t n = (uint32_t)names.size();
+        const size_t stride = (mi355_jpeg_scan_bound((uint32_t)W, (uint32_t)H) + 3) & ~(size_t)3;
+        std::vector<uint8_t> scans((size_t)n * stride), file;
+        std::vector<uint64_t> bits(n);
+        double secs = 0;
+        rc = mi355_jpeg_pool_encode(pool, frames.data(), (uint32_t)W, (uint32_t)H, n, flags, scans.data(), stride, bits.data(), &secs);
+        if (rc) {
+            std::cout << "mi355-jpeg: " << mi355_jpeg_strerror(rc) << std::endl;
+            status = 1;
+            break;
+        }
+        enc_seconds += secs;
+        px_total += (double)n * W * H;
+        for (uint32_t f = 0; f < n && !status; ++f) {
+            file.resize(2 * (size_t)((bits[f] + 7) / 8) + 4096);
+            size_t len = 0;
+            rc = mi355_jpeg_wrap_jfif(ctx, scans.data() + (size_t)f * stride, bits[f], (uint32_t)W, (uint32_t)H, flags,
+                                      file.data(), file.size(), &len);
+            const std::string out = (fs::path(out_dir) / fs::path(names[f]).stem()).string() + ".jpg";
+            FILE* fp = rc ? nullptr : fopen(out.c_str(), "wb");
+            if (!fp) {
+                std::cout << "mi355-jpeg: cannot write " << out << std::endl;
+                status = 1;
+                break;
+            }
+            fwrite(file.data(), 1, len, fp);
+            fclose(fp);
+        }
+        std::cout << "  " << n << " x " << W << "x" << H << ": " << secs * 1e3 << " ms encode incl. transfers" << std::endl;
+    }
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count();
+    if (!status)
+        std::cout << "Encoded " << px_total / 1e6 << " Mpixel: " << px_total / 1e6 / (enc_seconds > 0 ? enc_seconds : 1) << " Mpixel/s in the encode calls (PCIe-inclusive), "
+                  << px_total / 1e6 / wall << " Mpixel/s wall incl. file I/O" << std::endl;
+    mi355_jpeg_destroy(ctx);
+    mi355_jpeg_pool_destroy(pool);
+    return status;
 }
 
 int main(int argc, char** argv) {
     std::string in = "../data/fruit.ppm", out = "../data/fruit.jpg", bits_path;
     int quality = 50, device = 0, repeat = 1, pos = 0;
-    bool cds = true;
+    bool cds = true, batch = false;
     std::string mode = "strict", subsample;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -41,6 +142,8 @@ int main(int argc, char** argv) {
             quality = atoi(argv[++i]);
         } else if (a == "--no-cds") {
             cds = false;
+        } else if (a == "--batch") {
+            batch = true;
         } else if (a == "--mode" && i + 1 < argc) {
             mode = argv[++i];
         } else if (a == "--subsample" && i + 1 < argc) {
@@ -83,6 +186,13 @@ int main(int argc, char** argv) {
     } else {
         usage();
         return 2;
+    }
+    if (batch) {
+        if (pos != 2) {
+            usage();
+            return 2;
+        }
+        return run_batch(in, out, quality, mode_flags ? mode_flags : (cds ? MI355_F_CDS : 0u));
     }
     ppm_t img;
     if (readPPMImage(in.c_str(), &img.width, &img.height, &img.data) == -1) return 1;

@@ -320,6 +320,31 @@ def test_jfif_file_matches_oracle_framing(jpeg, enc):
     assert got == want
 
 
+def test_wrap_jfif_equals_encode_jfif(jpeg, enc):
+    """Host-side framing of a scan that came back from the device = the one-call file."""
+    rgb = ol.lcg_frame(200, 120, 9)
+    ql, qc = set_quality(enc, 70)
+    bits, nb = enc.encode_scan(rgb)
+    assert enc.wrap_jfif(bits[0], nb[0], 200, 120) == enc.encode_jfif(rgb)
+    f = jpeg.F_STANDARD | jpeg.F_420
+    bits, nb = enc.encode_scan(rgb, f)
+    assert enc.wrap_jfif(bits[0], nb[0], 200, 120, f) == enc.encode_jfif(rgb, f)
+    set_quality(enc, 50)
+
+
+def test_encode_waves_option_does_not_change_results(jpeg):
+    e2 = jpeg.Encoder(0)
+    rgb = ol.lcg_frame(640, 360, 2)
+    want = ol.oracle_encode(rgb)
+    for waves in (0, 1024, 64, 32):
+        e2.set_encode_waves(waves)
+        bits, nb = e2.encode_scan(rgb)
+        assert nb[0] == want.n_bits and np.array_equal(bits[0], want.bits), waves
+    with pytest.raises(jpeg.JpegError):
+        e2.set_encode_waves(33)
+    e2.close()
+
+
 def test_custom_huffman_table_roundtrip(jpeg, enc):
     code, length = enc.get_huffman(2)
     assert length[(3 << 4) | 4] == 17 and length[0x00] == 4 and length[0xF0] == 11

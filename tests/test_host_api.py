@@ -99,6 +99,42 @@ def test_cli_standard_mode_writes_a_decodable_jpeg(tmp_path, sub):
     assert subprocess.call([CLI, os.path.join(GOLD, "fruit.ppm"), out, "--mode", "standard", "--subsample", "ref420"]) == 2
 
 
+def write_ppm(path, rgb):
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]))
+        f.write(np.ascontiguousarray(rgb, np.uint8).tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["strict", "standard"])
+def test_cli_batch_directory_mode(tmp_path, mode):
+    """--batch: a directory of PPMs of two sizes (+ one broken file) through the multi-GPU pool; every
+    output equals the checker's framing of the checker's bits, i.e. the one-file form's bytes."""
+    subprocess.check_call(["make", "-s", "-C", PKG, "all", "host"])
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    frames = {"a0": ol.lcg_frame(96, 64, 1), "a1": ol.lcg_frame(96, 64, 2), "a2": ol.lcg_frame(96, 64, 3),
+              "b0": ol.lcg_frame(50, 33, 4), "b1": ol.lcg_frame(50, 33, 5)}
+    for k, v in frames.items():
+        write_ppm(src / (k + ".ppm"), v)
+    (src / "broken.ppm").write_bytes(b"P5\n1 1\n255\n\0")
+    args = [CLI, "--batch", str(src), str(dst), "-q", "80"]
+    if mode == "standard":
+        args += ["--mode", "standard", "--subsample", "420"]
+    out = subprocess.run(args, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    ql, qc = ol.quant_tables(80)
+    for k, rgb in frames.items():
+        if mode == "standard":
+            o = ol.oracle_std_encode(rgb, ql, qc, subsample=1)
+            want = ol.jfif_frame(o.bits, o.n_bits, rgb.shape[1], rgb.shape[0], ql, qc, 1)
+        else:
+            o = ol.oracle_encode(rgb, ql, qc, True)
+            want = ol.jfif_frame(o.bits, o.n_bits, rgb.shape[1], rgb.shape[0], ql, qc)
+        assert (dst / (k + ".jpg")).read_bytes() == want, k
+    assert not (dst / "broken.jpg").exists()
+
+
 def test_ppm_reader_accepts_wellformed_headers(tmp_path):
     """No GPU needed: the host reader takes the reference's strict 3-line form and every other
     well-formed P6/255 header (comments, arbitrary whitespace), and rejects bad input with -1
