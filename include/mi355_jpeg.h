@@ -57,6 +57,13 @@ enum mi355_jpeg_status {
                                 Coefficient probe row order: luma 4*mcu + k (scan order), Cb at 4M + mcu, Cr at
                                 5M + mcu, M = MCUs.  (The reference's "subsampling" keeps full-resolution planes and
                                 is MI355_F_CDS.) */
+#define MI355_F_RESTART 8u   /* with MI355_F_STANDARD only: restart intervals of 64 MCUs (one tile of the device
+                                pipeline).  DC predictors start from 0 in every interval and every interval is
+                                padded to a byte boundary with 1s; mi355_jpeg_encode_jfif writes DRI and the RSTm
+                                markers between the intervals (a decoder can then resynchronise / decode intervals
+                                in parallel).  The scan entry points return the aligned intervals WITHOUT markers
+                                (markers must not be byte-stuffed, so they are added together with the stuffing);
+                                mi355_jpeg_wrap_jfif cannot add them afterwards and refuses the flag. */
 #define MI355_F_DEFAULT MI355_F_CDS
 
 /* One Huffman table in the form the kernels consume: index (run<<4)|size,

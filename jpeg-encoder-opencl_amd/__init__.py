@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libmi355jpeg.so")
 F_CDS = 1
 F_STANDARD = 2  # decodable baseline JPEG (not a behaviour of the reference), see include/mi355_jpeg.h
 F_420 = 4       # with F_STANDARD: real 4:2:0 MCUs
+F_RESTART = 8   # with F_STANDARD: restart intervals of 64 MCUs (DRI/RSTm written by encode_jfif)
 F_DEFAULT = F_CDS
 
 OK, E_ARG, E_NO_DEVICE, E_CAPACITY, E_CATEGORY, E_ALLOC, E_TABLE, E_HIP = 0, -1, -2, -3, -4, -5, -6, -100

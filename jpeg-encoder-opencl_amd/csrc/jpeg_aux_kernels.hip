@@ -60,14 +60,31 @@ __device__ __forceinline__ uint32_t scan_byte(const uint8_t* __restrict__ in, ui
     return b;
 }
 
+// Restart intervals (MI355_F_RESTART): tile t >= 1 starts at bit tile_off[t], a multiple of 8, and the marker
+// RST((t-1) & 7) goes in front of its first byte.  First tile in [1, tiles) that starts at or after `bit`.
+__device__ __forceinline__ uint32_t first_tile_from(const uint64_t* __restrict__ tile_off, uint32_t tiles, uint64_t bit) {
+    uint32_t lo = 1, hi = tiles;  // answer in [lo, hi]
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tile_off[mid] >= bit) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
 __global__ void __launch_bounds__(256)
-    k_stuff_count(const uint8_t* __restrict__ in, const uint64_t* __restrict__ nbits_p, uint32_t* __restrict__ counts) {
+    k_stuff_count(const uint8_t* __restrict__ in, const uint64_t* __restrict__ nbits_p, uint32_t* __restrict__ counts,
+                  const uint64_t* __restrict__ tile_off, uint32_t tiles) {
     __shared__ uint32_t s_sum[4];
     const uint64_t nbits = *nbits_p, nbytes = (nbits + 7) / 8;
     const uint64_t i0 = (uint64_t)blockIdx.x * kStuffChunk + threadIdx.x * 16;
     uint32_t n = 0;
     for (uint32_t j = 0; j < 16; ++j)
         if (i0 + j < nbytes && scan_byte(in, i0 + j, nbytes, nbits) == 0xFFu) ++n;
+    if (tile_off && i0 < nbytes) {  // two marker bytes per tile that starts among this thread's bytes
+        const uint64_t i1 = i0 + 16 < nbytes ? i0 + 16 : nbytes;
+        n += 2u * (first_tile_from(tile_off, tiles, 8 * i1) - first_tile_from(tile_off, tiles, 8 * i0));
+    }
     for (int d = 32; d; d >>= 1) n += __shfl_xor(n, d);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = n;
     __syncthreads();
@@ -103,7 +120,8 @@ __global__ void __launch_bounds__(1024)
 
 __global__ void __launch_bounds__(256)
     k_stuff_write(const uint8_t* __restrict__ in, const uint64_t* __restrict__ nbits_p, const uint64_t* __restrict__ offs,
-                  uint8_t* __restrict__ out, uint64_t cap, uint32_t* __restrict__ status) {
+                  uint8_t* __restrict__ out, uint64_t cap, uint32_t* __restrict__ status,
+                  const uint64_t* __restrict__ tile_off, uint32_t tiles) {
     __shared__ uint32_t s_wave[4];
     const uint64_t nbits = *nbits_p, nbytes = (nbits + 7) / 8;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,6 +130,12 @@ __global__ void __launch_bounds__(256)
     for (uint32_t j = 0; j < 16; ++j) {
         b[j] = i0 + j < nbytes ? scan_byte(in, i0 + j, nbytes, nbits) : 0u;
         n += (i0 + j < nbytes && b[j] == 0xFFu) ? 1u : 0u;
+    }
+    uint32_t next_tile = tiles;  // next tile whose start is at or after this thread's first byte
+    if (tile_off && i0 < nbytes) {
+        const uint64_t i1 = i0 + 16 < nbytes ? i0 + 16 : nbytes;
+        next_tile = first_tile_from(tile_off, tiles, 8 * i0);
+        n += 2u * (first_tile_from(tile_off, tiles, 8 * i1) - next_tile);
     }
     uint32_t incl = n;
     for (int d = 1; d < 64; d <<= 1) {
@@ -125,9 +149,14 @@ __global__ void __launch_bounds__(256)
     uint64_t o = i0 + offs[blockIdx.x] + pre + incl - n;  // output position of this thread's first byte
     for (uint32_t j = 0; j < 16; ++j) {
         if (i0 + j >= nbytes) break;
-        if (o + 2 > cap) {
+        if (o + 4 > cap) {
             atomicOr(status, 2u);  // MI355_E_CAPACITY
             return;
+        }
+        if (next_tile < tiles && tile_off[next_tile] == 8 * (i0 + j)) {  // RSTm in front of the tile's first byte
+            out[o++] = 0xFF;
+            out[o++] = (uint8_t)(0xD0u + ((next_tile - 1u) & 7u));
+            ++next_tile;
         }
         out[o++] = (uint8_t)b[j];
         if (b[j] == 0xFFu) out[o++] = 0;
@@ -136,12 +165,13 @@ __global__ void __launch_bounds__(256)
 
 hipError_t launch_stuff(const uint8_t* in, const uint64_t* d_nbits, uint64_t max_bytes, uint32_t* counts,
                         uint64_t* offs, uint64_t* d_total, uint8_t* out, uint64_t cap, uint32_t* status,
-                        hipStream_t s) {
+                        const uint64_t* tile_off, uint32_t tiles, hipStream_t s) {
     const uint32_t chunks = (uint32_t)((max_bytes + kStuffChunk - 1) / kStuffChunk);
     if (chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_stuff_count, dim3(chunks), dim3(256), 0, s, in, d_nbits, counts);
+    hipLaunchKernelGGL(k_stuff_count, dim3(chunks), dim3(256), 0, s, in, d_nbits, counts, tile_off, tiles);
     hipLaunchKernelGGL(k_stuff_scan, dim3(1), dim3(1024), 0, s, counts, offs, chunks, d_total, d_nbits);
-    hipLaunchKernelGGL(k_stuff_write, dim3(chunks), dim3(256), 0, s, in, d_nbits, offs, out, cap, status);
+    hipLaunchKernelGGL(k_stuff_write, dim3(chunks), dim3(256), 0, s, in, d_nbits, offs, out, cap, status, tile_off,
+                       tiles);
     return hipGetLastError();
 }
 

@@ -67,7 +67,8 @@ hipError_t launch_lcg_fill(uint8_t* dst, uint64_t frame_bytes, uint32_t n_frames
 // stuffs ceil(*d_nbits/8) bytes (<= max_bytes) of `in` into `out`; *d_total = stuffed length in bytes
 hipError_t launch_stuff(const uint8_t* in, const uint64_t* d_nbits, uint64_t max_bytes, uint32_t* counts,
                         uint64_t* offs, uint64_t* d_total, uint8_t* out, uint64_t cap, uint32_t* status,
-                        hipStream_t s);
+                        const uint64_t* tile_off /* restart intervals: [tiles] byte-aligned bit offsets, or nullptr */,
+                        uint32_t tiles, hipStream_t s);
 
 hipError_t launch_transform(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const double* qd,
                             uint32_t* coefs, int mode, hipStream_t s);

@@ -194,8 +194,10 @@ __global__ void __launch_bounds__(1024)
     const uint32_t per = (g.tiles + 1023u) / 1024u;
     const uint32_t lo = tid * per < g.tiles ? tid * per : g.tiles;
     const uint32_t hi = lo + per < g.tiles ? lo + per : g.tiles;
+    // restart intervals (standard mode, MI355_F_RESTART): every tile starts on a byte boundary
+    const uint32_t pad = (g.flags & 8u) ? 7u : 0u;
     uint64_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += tb[i];
+    for (uint32_t i = lo; i < hi; ++i) sum += (tb[i] + pad) & ~pad;
     uint64_t incl = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(1024)
         to[i] = run;
         // word shared with the previous tile: both sides OR into it
         if (i > 0 && (run & 31) && (run >> 5) * 4 + 4 <= out_stride) outw[run >> 5] = 0;
-        run += tb[i];
+        run += (tb[i] + pad) & ~pad;
         if (rearm_tiles) tb[i] = 0;
     }
     if (tid == 1023) {

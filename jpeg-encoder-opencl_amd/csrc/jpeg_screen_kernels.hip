@@ -1078,8 +1078,9 @@ __global__ void __launch_bounds__(64)
     if (lane < 32) s_dcf[lane >> 4][lane & 15] = sp.lut[(lane >> 4) * 256 + (lane & 15)];
     __syncthreads();
     const uint32_t P = g.passes, heads = n_frames * g.tiles * P;
+    const bool restart = (g.flags & 8u) != 0;  // MI355_F_RESTART: DC predictors start from 0 in every tile
     for (uint32_t p = blockIdx.x * 64 + lane; p < heads; p += gridDim.x * 64) {
-        const uint32_t ft = p / P, c = p - ft * P, tile = ft % g.tiles;
+        const uint32_t ft = p / P, c = p - ft * P, tile = restart ? 0u : ft % g.tiles;
         const size_t u0 = (size_t)p * 64;  // ((frame * tiles + tile) * passes + c) * 64
         int pred = 0;
         bool luma = c == 0;
@@ -1087,7 +1088,7 @@ __global__ void __launch_bounds__(64)
             // 4:2:0: luma quarter-tile c follows quarter-tile c - 1 (or the previous tile's quarter-tile 3);
             // a quarter-tile past the last MCU has no units at all
             luma = c < 4;
-            if (luma && tile * 64 + 16 * c >= g.N) continue;
+            if (luma && (ft % g.tiles) * 64 + 16 * c >= g.N) continue;
             if (luma && c > 0) pred = meta_dc(sp.meta[u0 - 64 + 63].y);
             else if (tile > 0) pred = meta_dc(sp.meta[u0 - 6 * 64 + (luma ? 3 * 64 : 0) + 63].y);
         } else if (tile > 0) {
@@ -1181,6 +1182,9 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
     const bool use_lds = nw <= lds_words_limit;
     uint32_t* outw = reinterpret_cast<uint32_t*>(out + (size_t)frame * out_stride);
     const bool last_tile = tile + 1 == g.tiles;
+    const bool restart = (g.flags & 8u) != 0;          // MI355_F_RESTART
+    const uint32_t ptile = restart ? 0u : tile;        // "no previous tile" for the DC predictors
+    const uint32_t last_blk = g.N - 1 - tile * 64 < 63 ? g.N - 1 - tile * 64 : 63;  // last active block / MCU
     if (tid < 32) s_dc[tid >> 4][tid & 15] = lut[(tid >> 4) * 256 + (tid & 15)];
     if (use_lds) {
         for (uint32_t i = tid; i < nw; i += NT) s_words[i] = 0;
@@ -1191,7 +1195,7 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
         }
     }
     // this unit: DC, AC length, arena offset; the first words of its AC string are fetched now
-    bool active, chroma;
+    bool active, chroma, tile_end;  // tile_end: the last unit of the tile's scan
     uint32_t spos;  // position of the unit in the tile's scan
     uint2 m;
     int dc, pred;
@@ -1201,26 +1205,29 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
         spos = tid;
         chroma = k >= 4;
         active = tile * 64 + mcu < g.N;
+        tile_end = mcu == last_blk && k == 5;
         pred = 0;
         if (!chroma) {
             const uint32_t L = 4 * mcu + k;  // pass L >> 6, lane L & 63: slot t0 + L
             m = meta[t0 + L];
             if (L > 0) pred = meta_dc(meta[t0 + L - 1].y);
-            else if (tile > 0) pred = meta_dc(meta[t0 - 6 * 64 + 3 * 64 + 63].y);
+            else if (ptile > 0) pred = meta_dc(meta[t0 - 6 * 64 + 3 * 64 + 63].y);
         } else {
             const size_t slot = t0 + (size_t)k * 64 + mcu;
             m = meta[slot];
             if (mcu > 0) pred = meta_dc(meta[slot - 1].y);
-            else if (tile > 0) pred = meta_dc(meta[slot - 6 * 64 + 63].y);
+            else if (ptile > 0) pred = meta_dc(meta[slot - 6 * 64 + 63].y);
         }
         dc = meta_dc(m.y);
     } else {
         spos = lane * 3 + chan;
         chroma = chan != 0;
         active = tile * 64 + lane < g.N;
+        tile_end = lane == last_blk && chan == 2;
         m = meta[((ft0 + tile) * 3 + chan) * 64 + lane];
         dc = meta_dc(m.y);
-        pred = meta_pred(meta, ft0, tile, chan, lane, dc);
+        pred = meta_pred(meta, ft0, ptile, chan, lane, dc);
+        if (restart && lane == 0) pred = 0;
     }
     const uint32_t aclen = active ? (m.y >> 16) : 0u;
     uint32_t pre[4];
@@ -1263,6 +1270,10 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
                 uint32_t w = arena[m.x + (done >> 5)];
                 uint32_t len = aclen - done < 32u ? aclen - done : 32u;
                 bw.put(w >> (32u - len), len);
+            }
+            if (restart && tile_end) {  // the interval ends on a byte boundary, filled with 1s (its start is aligned)
+                const uint32_t fill = (8u - (uint32_t)((pos + dcl + aclen) & 7u)) & 7u;
+                if (fill) bw.put((1u << fill) - 1u, fill);
             }
             bw.flush();
         };

@@ -163,6 +163,10 @@ struct mi355_jpeg_ctx {
 
 namespace {
 
+// d_tile_off: restart intervals (the frame's [tiles] byte-aligned tile offsets) or nullptr
+int stuff_scan(mi355_jpeg_ctx* c, const void* d_scan, const uint64_t* d_bits, size_t max_scan_bytes, void* d_out,
+               size_t cap, uint64_t* d_out_len, const uint64_t* d_tile_off, uint32_t tiles, void* stream);
+
 inline int hip_err(hipError_t e) { return e == hipSuccess ? MI355_OK : MI355_E_HIP - (int)e; }
 #define HIP_TRY(x)                             \
     do {                                       \
@@ -285,6 +289,7 @@ int upload_afrag(mi355_jpeg_ctx* c) {
 int make_geom(uint32_t W, uint32_t H, uint32_t flags, const void* base, Geom* g) {
     if (W == 0 || H == 0 || W > 65535u || H > 65535u) return MI355_E_ARG;
     if ((flags & MI355_F_420) && !(flags & MI355_F_STANDARD)) return MI355_E_ARG;  // real 4:2:0 MCUs: standard mode only
+    if ((flags & MI355_F_RESTART) && !(flags & MI355_F_STANDARD)) return MI355_E_ARG;
     const bool s420 = (flags & MI355_F_420) != 0;
     const uint32_t A = s420 ? 16 : 8;  // MCU edge
     uint32_t W8 = (W + A - 1) / A * A, H8 = (H + A - 1) / A * A;
@@ -927,6 +932,7 @@ size_t jfif_header(const mi355_jpeg_ctx* c, uint32_t W, uint32_t H, uint32_t fla
     dht_segment(w, 0x10, ht[2]);
     dht_segment(w, 0x01, ht[1]);
     dht_segment(w, 0x11, ht[3]);
+    if (flags & MI355_F_RESTART) w.w(0xFFDD), w.w(4), w.w(64);  // DRI: one interval = one 64-MCU tile
     w.w(0xFFDA), w.w(12), w.b(3);
     w.b(1), w.b(0x00), w.b(2), w.b(0x11), w.b(3), w.b(0x11);
     w.b(0), w.b(63), w.b(0);
@@ -938,6 +944,7 @@ int mi355_jpeg_wrap_jfif(mi355_jpeg_ctx* c, const uint8_t* scan, uint64_t n_bits
                          uint8_t* out, size_t cap, size_t* out_len) {
     if (!c || !scan || !out || !out_len || W == 0 || H == 0 || W > 65535u || H > 65535u) return MI355_E_ARG;
     if ((flags & MI355_F_420) && !(flags & MI355_F_STANDARD)) return MI355_E_ARG;
+    if (flags & MI355_F_RESTART) return MI355_E_ARG;  // the markers go in with the stuffing, on the device
     Writer w{out, jfif_header(c, W, H, flags, out, cap), cap};
     const size_t nb = (size_t)((n_bits + 7) / 8);
     for (size_t i = 0; i < nb; ++i) {  // entropy bytes: last partial byte padded with 1s, 0xFF -> 0xFF 0x00
@@ -974,8 +981,8 @@ int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, ui
         const size_t stuffed_cap = 2 * scan_cap + 16;
         if ((e = ensure(c->d_out, c->out_cap, scan_cap + stuffed_cap))) return e;
         e = mi355_jpeg_encode_scan_device(c, c->d_in, W, H, 1, flags, c->d_out, scan_cap, c->d_bits, nullptr);
-        if (!e) e = mi355_jpeg_stuff_device(c, c->d_out, c->d_bits, scan_cap, c->d_out + scan_cap, stuffed_cap,
-                                            c->d_bits + 1, nullptr);
+        if (!e) e = stuff_scan(c, c->d_out, c->d_bits, scan_cap, c->d_out + scan_cap, stuffed_cap, c->d_bits + 1,
+                               (flags & MI355_F_RESTART) ? c->d_tile_off : nullptr, g.tiles, nullptr);
         if (!e) e = mi355_jpeg_sync(c, nullptr);
         if (e == MI355_E_CAPACITY && attempt == 0 && scan_cap < bound) {
             scan_cap = bound;
@@ -1007,6 +1014,13 @@ int mi355_jpeg_synth_lcg_device(mi355_jpeg_ctx* c, void* d_dst, size_t frame_byt
 
 int mi355_jpeg_stuff_device(mi355_jpeg_ctx* c, const void* d_scan, const uint64_t* d_bits, size_t max_scan_bytes,
                             void* d_out, size_t cap, uint64_t* d_out_len, void* stream) {
+    return stuff_scan(c, d_scan, d_bits, max_scan_bytes, d_out, cap, d_out_len, nullptr, 0, stream);
+}
+
+}  // extern "C"
+namespace {
+int stuff_scan(mi355_jpeg_ctx* c, const void* d_scan, const uint64_t* d_bits, size_t max_scan_bytes, void* d_out,
+               size_t cap, uint64_t* d_out_len, const uint64_t* d_tile_off, uint32_t tiles, void* stream) {
     if (!c || !d_scan || !d_bits || !d_out || !d_out_len || max_scan_bytes == 0) return MI355_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     const size_t chunks = (max_scan_bytes + 4095) / 4096;
@@ -1015,10 +1029,12 @@ int mi355_jpeg_stuff_device(mi355_jpeg_ctx* c, const void* d_scan, const uint64_
     if ((e = ensure(c->d_stuff_offs, c->stuff_offs_cap, chunks + 1))) return e;
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(launch_stuff((const uint8_t*)d_scan, d_bits, max_scan_bytes, c->d_stuff_counts, c->d_stuff_offs,
-                         c->d_stuff_offs + chunks, (uint8_t*)d_out, cap, c->d_status, s));
+                         c->d_stuff_offs + chunks, (uint8_t*)d_out, cap, c->d_status, d_tile_off, tiles, s));
     HIP_TRY(hipMemcpyAsync(d_out_len, c->d_stuff_offs + chunks, sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
     return MI355_OK;
 }
+}  // namespace
+extern "C" {
 
 // ---- multi-GPU batch driver ----------------------------------------------------------
 //

@@ -11,7 +11,8 @@
 // --mode strict (default): the reference's arithmetic; --subsample ref420 (default) = its performCDS
 // (2x2 chroma means written back at full resolution), none (= --no-cds) skips it.
 // --mode standard: a decodable baseline JPEG (not a behaviour of the reference); --subsample 420
-// (default there) = real 16x16 MCUs, 444 = one block per component.
+// (default there) = real 16x16 MCUs, 444 = one block per component; --restart adds DRI + RSTm markers
+// every 64 MCUs.
 //
 // With no arguments, run from a build/ directory like the reference
 // (README.md:43, src/OpenCLProject_JpegEncoder.cpp:320): read ../data/fruit.ppm and
@@ -32,7 +33,7 @@
 
 static void usage() {
     std::cout << "usage: mi355-jpeg in.ppm out.jpg [-q 1..100] [--mode strict|standard] [--subsample ref420|none|420|444]\n"
-                 "                  [--no-cds] [--device K] [--repeat R] [--bits file]\n"
+                 "                  [--restart] [--no-cds] [--device K] [--repeat R] [--bits file]\n"
                  "       mi355-jpeg --batch IN_DIR OUT_DIR [-q ..] [--mode ..] [--subsample ..]   (all visible GPUs)\n"
                  "       (no arguments: ../data/fruit.ppm -> ../data/fruit.jpg, like the reference's fixed paths)\n";
 }
@@ -131,7 +132,7 @@ static int run_batch(const std::string& in_dir, const std::string& out_dir, int 
 int main(int argc, char** argv) {
     std::string in = "../data/fruit.ppm", out = "../data/fruit.jpg", bits_path;
     int quality = 50, device = 0, repeat = 1, pos = 0;
-    bool cds = true, batch = false;
+    bool cds = true, batch = false, restart = false;
     std::string mode = "strict", subsample;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -144,6 +145,8 @@ int main(int argc, char** argv) {
             cds = false;
         } else if (a == "--batch") {
             batch = true;
+        } else if (a == "--restart") {
+            restart = true;
         } else if (a == "--mode" && i + 1 < argc) {
             mode = argv[++i];
         } else if (a == "--subsample" && i + 1 < argc) {
@@ -186,6 +189,13 @@ int main(int argc, char** argv) {
     } else {
         usage();
         return 2;
+    }
+    if (restart) {  // DRI/RSTm every 64 MCUs: standard mode, one-file form (the markers go in with the device-side stuffing)
+        if (!mode_flags || batch) {
+            usage();
+            return 2;
+        }
+        mode_flags |= MI355_F_RESTART;
     }
     if (batch) {
         if (pos != 2) {

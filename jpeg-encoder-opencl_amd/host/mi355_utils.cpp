@@ -193,7 +193,7 @@ int mi355_select(int device, int quality) {
     return ensure_ctx();
 }
 
-void mi355_set_mode(unsigned mode_flags) { g_mode = mode_flags & (MI355_F_STANDARD | MI355_F_420); }
+void mi355_set_mode(unsigned mode_flags) { g_mode = mode_flags & (MI355_F_STANDARD | MI355_F_420 | MI355_F_RESTART); }
 
 int JpegEncoderDevice(ppm_t img, GPUTelemetry* tel, std::string* scanData, bool cds) {
     if (ensure_ctx()) return 1;

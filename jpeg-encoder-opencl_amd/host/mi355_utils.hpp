@@ -63,7 +63,7 @@ void getNearest8x8ImageSize(size_t width, size_t height, size_t* newWidth, size_
 // JpegEncoderHost.
 int mi355_select(int device, int quality);
 // Encode mode of the calls below.  0 (default) = strict: the reference's arithmetic, scan bits identical
-// to its CPU path.  MI355_F_STANDARD [| MI355_F_420] = decodable baseline JPEG, 4:4:4 or 4:2:0 (not a
+// to its CPU path.  MI355_F_STANDARD [| MI355_F_420] [| MI355_F_RESTART] = decodable baseline JPEG, 4:4:4 or 4:2:0 (not a
 // behaviour of the reference; chroma_downsample is ignored there).  See include/mi355_jpeg.h.
 void mi355_set_mode(unsigned mode_flags);
 

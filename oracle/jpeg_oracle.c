@@ -527,16 +527,17 @@ static void std_block(const int32_t p[64], const uint32_t *q, const uint8_t zz[6
     }
 }
 
-int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
-                   const uint32_t qchrom[64], const int64_t *dct, int subsample, int keep, orc_result *out) {
-    if (!rgb || !out || !dct || W == 0 || H == 0 || subsample < 0 || subsample > 1) return ORC_E_ARG;
-    memset(out, 0, sizeof *out);
+/* colour conversion, padding, (4:2:0: chroma means), exact fixed-point DCT + quantisation.
+ * Returns the malloc'd zig-zag rows (layout: see orc_std_encode) or NULL for a refused size. */
+static int32_t *std_transform(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
+                              const uint32_t qchrom[64], const int64_t *dct, int subsample, size_t *Wp_out,
+                              size_t *Hp_out, size_t *M_out) {
     const size_t A = subsample ? 16 : 8; /* MCU edge in pixels */
     const size_t Wp = (W + A - 1) / A * A, Hp = (H + A - 1) / A * A;
-    if (Wp - W > W || Hp - H > H) return ORC_E_ARG;
+    if (Wp - W > W || Hp - H > H) return NULL;
     const size_t M = (Wp / A) * (Hp / A);            /* MCUs */
     const size_t units = subsample ? 6 * M : 3 * M;  /* 8x8 blocks in the scan */
-    out->W8 = Wp, out->H8 = Hp, out->n_blocks = M;
+    *Wp_out = Wp, *Hp_out = Hp, *M_out = M;
     uint8_t *img = (uint8_t *)malloc(W * H * 3), *pad = (uint8_t *)malloc(Wp * Hp * 3);
     int32_t *zig = (int32_t *)malloc(units * 64 * sizeof(int32_t));
     for (size_t i = 0; i < W * H; ++i) {
@@ -588,6 +589,26 @@ int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[6
             }
     }
     free(pad);
+    return zig;
+}
+
+/* one unit's place in the row array for MCU i, block k of the MCU (see orc_std_encode) */
+static const int32_t *std_row(const int32_t *zig, size_t M, int subsample, size_t i, int k, int *comp) {
+    const int c = subsample ? (k < 4 ? 0 : k - 3) : k;
+    *comp = c;
+    if (subsample) return k < 4 ? zig + (4 * i + k) * 64 : zig + ((size_t)(3 + c) * M + i) * 64;
+    return zig + (i + M * (size_t)c) * 64;
+}
+
+int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
+                   const uint32_t qchrom[64], const int64_t *dct, int subsample, int keep, orc_result *out) {
+    if (!rgb || !out || !dct || W == 0 || H == 0 || subsample < 0 || subsample > 1) return ORC_E_ARG;
+    memset(out, 0, sizeof *out);
+    size_t Wp, Hp, M;
+    int32_t *zig = std_transform(rgb, W, H, qlum, qchrom, dct, subsample, &Wp, &Hp, &M);
+    if (!zig) return ORC_E_ARG;
+    const size_t units = subsample ? 6 * M : 3 * M;
+    out->W8 = Wp, out->H8 = Hp, out->n_blocks = M;
     if (keep & ORC_KEEP_UNIT_BITS) out->unit_bits = (uint32_t *)malloc(units * sizeof(uint32_t));
     struct orc_bitsink sink = {0, 0, 0};
     int32_t pred[3] = {0, 0, 0};
@@ -596,9 +617,8 @@ int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[6
     const int per_mcu = subsample ? 6 : 3;
     for (size_t i = 0; i < M && !err; ++i)
         for (int k = 0; k < per_mcu; ++k, ++u) {
-            const int c = subsample ? (k < 4 ? 0 : k - 3) : k;
-            const int32_t *r = subsample ? (k < 4 ? zig + (4 * i + k) * 64 : zig + ((size_t)(3 + c) * M + i) * 64)
-                                         : zig + (i + M * (size_t)c) * 64;
+            int c;
+            const int32_t *r = std_row(zig, M, subsample, i, k, &c);
             int32_t diff = r[0] - pred[c];
             pred[c] = r[0];
             int n = std_unit(r, diff, c != 0, &sink);
@@ -664,9 +684,72 @@ long orc_jfif_frame(const uint8_t *bits, uint64_t n_bits, size_t W, size_t H,
 }
 
 /* subsample 1: luma sampling factors 2x2 (4:2:0 MCUs), else 1x1 */
+static void jfif_header(wr *wp, size_t W, size_t H, const uint32_t qlum[64], const uint32_t qchrom[64],
+                        int subsample, unsigned restart_interval);
+
 long orc_jfif_frame_s(const uint8_t *bits, uint64_t n_bits, size_t W, size_t H, const uint32_t qlum[64],
                       const uint32_t qchrom[64], int subsample, uint8_t *out, size_t cap) {
     wr w = {out, 0, cap, 0};
+    jfif_header(&w, W, H, qlum, qchrom, subsample, 0);
+    size_t nb = (size_t)((n_bits + 7) / 8);
+    for (size_t i = 0; i < nb; ++i) {
+        unsigned b = bits[i];
+        if (i == nb - 1 && (n_bits & 7)) b |= 0xFFu >> (n_bits & 7); /* pad with 1s */
+        w8(&w, b);
+        if (b == 0xFF) w8(&w, 0);
+    }
+    w16(&w, 0xFFD9);
+    return w.ovf ? ORC_E_CAPACITY : (long)w.n;
+}
+
+/* Standard mode with restart markers: DRI = `interval` MCUs; every interval starts with zero DC
+ * predictors, is padded to a byte with 1s and (except the last) followed by RSTm, m = index mod 8.
+ * Writes the whole file. */
+long orc_std_jfif_restart(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
+                          const uint32_t qchrom[64], const int64_t *dct, int subsample, unsigned interval,
+                          uint8_t *out, size_t cap) {
+    if (!rgb || !dct || !out || W == 0 || H == 0 || interval == 0 || interval > 65535) return ORC_E_ARG;
+    size_t Wp, Hp, M;
+    int32_t *zig = std_transform(rgb, W, H, qlum, qchrom, dct, subsample, &Wp, &Hp, &M);
+    if (!zig) return ORC_E_ARG;
+    wr w = {out, 0, cap, 0};
+    jfif_header(&w, W, H, qlum, qchrom, subsample, interval);
+    const int per_mcu = subsample ? 6 : 3;
+    int err = 0;
+    for (size_t i0 = 0, idx = 0; i0 < M && !err; i0 += interval, ++idx) {
+        struct orc_bitsink sink = {0, 0, 0};
+        int32_t pred[3] = {0, 0, 0};
+        const size_t i1 = i0 + interval < M ? i0 + interval : M;
+        for (size_t i = i0; i < i1 && !err; ++i)
+            for (int k = 0; k < per_mcu; ++k) {
+                int c;
+                const int32_t *r = std_row(zig, M, subsample, i, k, &c);
+                int32_t diff = r[0] - pred[c];
+                pred[c] = r[0];
+                if (std_unit(r, diff, c != 0, &sink) < 0) {
+                    err = ORC_E_CATEGORY;
+                    break;
+                }
+            }
+        const size_t nb = (size_t)((sink.nbit + 7) / 8);
+        for (size_t i = 0; i < nb; ++i) {
+            unsigned b = sink.buf[i];
+            if (i == nb - 1 && (sink.nbit & 7)) b |= 0xFFu >> (sink.nbit & 7);
+            w8(&w, b);
+            if (b == 0xFF) w8(&w, 0);
+        }
+        free(sink.buf);
+        if (i1 < M) w16(&w, 0xFFD0 + (unsigned)(idx & 7));
+    }
+    free(zig);
+    w16(&w, 0xFFD9);
+    if (err) return err;
+    return w.ovf ? ORC_E_CAPACITY : (long)w.n;
+}
+
+static void jfif_header(wr *wp, size_t W, size_t H, const uint32_t qlum[64], const uint32_t qchrom[64],
+                        int subsample, unsigned restart_interval) {
+    wr w = *wp;
     uint8_t zz[64];
     orc_zigzag_order(zz);
     w16(&w, 0xFFD8);
@@ -686,16 +769,9 @@ long orc_jfif_frame_s(const uint8_t *bits, uint64_t n_bits, size_t W, size_t H, 
     dht(&w, 0x10, BITS_AC_L, VAL_AC_L, 162);
     dht(&w, 0x01, BITS_DC_C, VAL_DC, 12);
     dht(&w, 0x11, BITS_AC_C, VAL_AC_C, 162);
+    if (restart_interval) w16(&w, 0xFFDD), w16(&w, 4), w16(&w, restart_interval);
     w16(&w, 0xFFDA), w16(&w, 12), w8(&w, 3);
     w8(&w, 1), w8(&w, 0x00), w8(&w, 2), w8(&w, 0x11), w8(&w, 3), w8(&w, 0x11);
     w8(&w, 0), w8(&w, 63), w8(&w, 0);
-    size_t nb = (size_t)((n_bits + 7) / 8);
-    for (size_t i = 0; i < nb; ++i) {
-        unsigned b = bits[i];
-        if (i == nb - 1 && (n_bits & 7)) b |= 0xFFu >> (n_bits & 7); /* pad with 1s */
-        w8(&w, b);
-        if (b == 0xFF) w8(&w, 0);
-    }
-    w16(&w, 0xFFD9);
-    return w.ovf ? ORC_E_CAPACITY : (long)w.n;
+    *wp = w;
 }

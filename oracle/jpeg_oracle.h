@@ -116,6 +116,11 @@ int orc_entropy(const int32_t *zigzag, size_t n_blocks, uint8_t **bits, size_t *
  *            then Cb at 4M + mcu, Cr at 5M + mcu; n_blocks = M (MCUs); unit_bits in scan order. */
 int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
                    const uint32_t qchrom[64], const int64_t *dct, int subsample, int keep, orc_result *out);
+/* The whole file of standard mode WITH restart markers (DRI = interval MCUs): every interval starts
+ * from zero DC predictors, is padded to a byte with 1s and, except the last, followed by RSTm. */
+long orc_std_jfif_restart(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
+                          const uint32_t qchrom[64], const int64_t *dct, int subsample, unsigned interval,
+                          uint8_t *out, size_t cap);
 long orc_jfif_frame_s(const uint8_t *bits, uint64_t n_bits, size_t W, size_t H, const uint32_t qlum[64],
                       const uint32_t qchrom[64], int subsample, uint8_t *out, size_t cap);
 

@@ -59,6 +59,9 @@ def oracle():
         L.orc_std_encode.restype = C.c_int
         L.orc_std_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.POINTER(OrcResult)]
+        L.orc_std_jfif_restart.restype = C.c_long
+        L.orc_std_jfif_restart.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_uint, C.c_void_p, C.c_size_t]
         L.orc_jfif_frame_s.restype = C.c_long
         L.orc_jfif_frame_s.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -230,6 +233,22 @@ def oracle_std_encode(rgb, qlum, qchrom, keep=0, subsample=0):
     out.unit_bits = np.ctypeslib.as_array(res.unit_bits, (units,)).copy() if res.unit_bits else None
     oracle().orc_result_free(C.byref(res))
     return out
+
+
+def oracle_std_jfif_restart(rgb, qlum, qchrom, subsample=0, interval=64):
+    """Whole file of standard mode with restart markers every `interval` MCUs."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    H, W, _ = rgb.shape
+    qlum = np.ascontiguousarray(qlum, np.uint32)
+    qchrom = np.ascontiguousarray(qchrom, np.uint32)
+    dct = np.ascontiguousarray(std_dct_table(), np.int64)
+    cap = 4 * W * H * 3 + (1 << 16)
+    out = np.empty(cap, np.uint8)
+    n = oracle().orc_std_jfif_restart(rgb.ctypes.data, W, H, qlum.ctypes.data, qchrom.ctypes.data, dct.ctypes.data,
+                                      subsample, interval, out.ctypes.data, cap)
+    if n <= 0:
+        raise RuntimeError("orc_std_jfif_restart failed: %d" % n)
+    return out[:n].tobytes()
 
 
 def ref_encode(rgb, qlum=None, qchrom=None, cds_on=True, keep=0):

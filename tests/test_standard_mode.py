@@ -118,6 +118,23 @@ def test_division_constants():
     assert (((s * 8796094) >> 38) == s // 31250).all() and 8796094 < 2 ** 24
 
 
+@pytest.mark.parametrize("ss", [0, 1])
+def test_oracle_restart_files_decode_to_the_same_pixels(ss):
+    """DRI/RSTm: every 64-MCU interval starts from zero predictors and ends on a byte boundary; a
+    decoder must produce exactly the pixels of the file without restart markers."""
+    rgb = smooth_frame(333, 201, 4)
+    ql, qc = ol.quant_tables(85)
+    f = ol.oracle_std_jfif_restart(rgb, ql, qc, ss, 64)
+    o = ol.oracle_std_encode(rgb, ql, qc, subsample=ss)
+    plain = ol.jfif_frame(o.bits, o.n_bits, 333, 201, ql, qc, ss)
+    assert b"\xff\xdd\x00\x04\x00\x40" in f and b"\xff\xdd" not in plain
+    n_mcu = ((333 + 15) // 16) * ((201 + 15) // 16) if ss else ((333 + 7) // 8) * ((201 + 7) // 8)
+    sos = f.index(b"\xff\xda")
+    markers = [f[i + 1] for i in range(sos + 14, len(f) - 2) if f[i] == 0xFF and 0xD0 <= f[i + 1] <= 0xD7]
+    assert markers == [0xD0 + (i & 7) for i in range((n_mcu + 63) // 64 - 1)]
+    assert np.array_equal(pil_decode(f), pil_decode(plain))
+
+
 def test_oracle_standard_coefficients_against_float_dct():
     """Independent arithmetic: scipy's orthonormal fp64 DCT-II of the same samples, divided and
     rounded half away, gives the same integers except within 1e-6 of a rounding tie."""
@@ -271,4 +288,24 @@ def test_gpu_420_jfif_decodes_and_batches(jpeg, enc):
         assert nb[f] == w.n_bits and np.array_equal(bits[f], w.bits)
     with pytest.raises(jpeg.JpegError):  # 4:2:0 MCUs exist in standard mode only
         enc.encode_scan(rgb, jpeg.F_420)
+    enc.set_quality(50)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,q,ss,kind", [(333, 201, 85, 0, "smooth"), (333, 201, 85, 1, "smooth"), (1920, 1080, 75, 1, "lcg"),
+                                          (640, 368, 50, 0, "lcg"), (16, 16, 90, 1, "lcg"), (1024, 1024, 100, 0, "lcg"),
+                                          (3840, 2160, 50, 1, "lcg")])
+def test_gpu_restart_intervals_equal_checker(jpeg, enc, W, H, q, ss, kind):
+    """MI355_F_RESTART: the device writes the same file as the checker (DRI, aligned intervals, RSTm
+    inserted together with the byte stuffing); Pillow decodes it to the pixels of the plain file."""
+    rgb = ol.lcg_frame(W, H, 3) if kind == "lcg" else smooth_frame(W, H, 4)
+    ql, qc = ol.quant_tables(q)
+    enc.set_quant(ql, qc)
+    flags = jpeg.F_STANDARD | (jpeg.F_420 if ss else 0)
+    got = enc.encode_jfif(rgb, flags | jpeg.F_RESTART)
+    assert got == ol.oracle_std_jfif_restart(rgb, ql, qc, ss, 64)
+    if W * H <= 1920 * 1080:
+        assert np.array_equal(pil_decode(got), pil_decode(enc.encode_jfif(rgb, flags)))
+    with pytest.raises(jpeg.JpegError):  # restart intervals exist in standard mode only
+        enc.encode_jfif(rgb, jpeg.F_RESTART)
     enc.set_quality(50)
