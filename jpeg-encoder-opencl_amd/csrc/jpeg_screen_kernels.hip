@@ -34,6 +34,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // the zig-zag rows are written as packed uint32 pairs and read back as int16: tell TBAA
 typedef int16_t __attribute__((may_alias)) i16a;
 
+#ifndef MI355_WALK_UNROLL2
+#define MI355_WALK_UNROLL2 1
+#endif
+
 constexpr uint32_t kSlotWordsFull = 54;  // worst case 63*(17+10)+4 = 1705 bits
 
 // ----------------------------------------------------------------------------
@@ -562,6 +566,20 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
     WalkA a1 = stageA();
     WalkA a2 = stageA();
     WalkB b1 = stageB(a1);
+#if MI355_WALK_UNROLL2
+    // two symbols per trip: the pipeline registers rotate by renaming instead of by moves (an odd
+    // count runs one extra step on the sentinel, a no-op for every lane)
+    for (uint32_t i = 0; i < maxcnt; i += 2) {
+        WalkA a3 = stageA();
+        WalkB b2 = stageB(a2);
+        stageC(b1);
+        WalkA a4 = stageA();
+        WalkB b3 = stageB(a3);
+        stageC(b2);
+        a2 = a4;
+        b1 = b3;
+    }
+#else
     for (uint32_t i = 0; i < maxcnt; ++i) {
         WalkA a3 = stageA();
         WalkB b2 = stageB(a2);
@@ -569,6 +587,7 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
         a2 = a3;
         b1 = b2;
     }
+#endif
     // the reference appends EOB ALWAYS (quirk Q8); a standard encoder omits it after coefficient 63
     if (!(STD && (mask >> 63))) pk.put(lut2[kLut2Eob]);
     pk.finish();
