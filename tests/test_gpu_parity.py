@@ -518,6 +518,40 @@ def test_randomised_parity_sweep(jpeg, enc):
             assert np.array_equal(enc.probe_unit_bits(rgb, flags), o.unit_bits), (it, W, H, q, cds, kind)
 
 
+def test_pipelined_contexts_share_the_device(jpeg):
+    """The bench's shape: four contexts, four HIP streams, half the device per call, many calls in
+    flight with no synchronisation in between (block-encode kernels of different streams resident
+    side by side, tail kernels under them).  Every frame's bits must equal the oracle's."""
+    import torch
+    S, R, W, H = 4, 12, 640, 360
+    encs = [jpeg.Encoder(0) for _ in range(S)]
+    for e in encs:
+        e.set_encode_waves(1024)
+    frames = np.stack([ol.lcg_frame(W, H, 100 + i) for i in range(R)])
+    want = [ol.oracle_encode(f) for f in frames]
+    dev = torch.device("cuda", 0)
+    d_rgb = torch.from_numpy(frames).to(dev)
+    cap = 1 << 20
+    d_out = torch.zeros((R, cap), dtype=torch.uint8, device=dev)
+    d_bits = torch.zeros(R, dtype=torch.int64, device=dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i in range(R):
+            k = i % S
+            encs[k].encode_scan_device(d_rgb[i].data_ptr(), W, H, 1, d_out[i].data_ptr(), cap, d_bits[i:].data_ptr(),
+                                       stream=streams[k].cuda_stream)
+    for e, st in zip(encs, streams):
+        e.sync(st.cuda_stream)
+    bits = d_bits.cpu().numpy()
+    out = d_out.cpu().numpy()
+    for i in range(R):
+        assert bits[i] == want[i].n_bits, i
+        assert np.array_equal(out[i, :(bits[i] + 7) // 8], want[i].bits), i
+    for e in encs:
+        e.close()
+
+
 def test_two_contexts_two_threads(jpeg):
     """Contexts are independent: two host threads, each with its own context and stream on
     the same GPU, encode different batches concurrently."""

@@ -309,3 +309,41 @@ def test_gpu_restart_intervals_equal_checker(jpeg, enc, W, H, q, ss, kind):
     with pytest.raises(jpeg.JpegError):  # restart intervals exist in standard mode only
         enc.encode_jfif(rgb, jpeg.F_RESTART)
     enc.set_quality(50)
+
+
+@pytest.mark.gpu
+def test_gpu_standard_randomised_sweep(jpeg, enc):
+    """60 random cases over size (ragged, tiny, wide), quality, sampling, restart intervals and content."""
+    rng = np.random.default_rng(4202)
+    for it in range(60):
+        W = int(rng.choice([8, 16, 24, 40, 64, 100, 127, 255, 256, 320, 511, 640, 1000]))
+        H = int(rng.choice([8, 9, 16, 31, 48, 64, 100, 129, 240]))
+        ss = int(rng.integers(0, 2))
+        A = 16 if ss else 8
+        if (W + A - 1) // A * A - W > W or (H + A - 1) // A * A - H > H:
+            continue
+        kind = it % 4
+        if kind == 0:
+            rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        elif kind == 1:
+            rgb = smooth_frame(W, H, it)
+        elif kind == 2:
+            rgb = np.full((H, W, 3), rng.integers(0, 256, 3), np.uint8)
+        else:
+            rgb = (rng.integers(0, 2, (H, W, 1)) * rng.integers(100, 256)).astype(np.uint8).repeat(3, 2)
+        q = int(rng.choice([5, 25, 50, 75, 90, 97, 100]))
+        ql, qc = ol.quant_tables(q)
+        enc.set_quant(ql, qc)
+        flags = jpeg.F_STANDARD | (jpeg.F_420 if ss else 0)
+        try:
+            o = ol.oracle_std_encode(rgb, ql, qc, 0, subsample=ss)
+        except RuntimeError:  # a size category outside the tables (binary images at q100): both refuse
+            with pytest.raises(jpeg.JpegError):
+                enc.encode_scan(rgb, flags)
+            continue
+        bits, nb = enc.encode_scan(rgb, flags)
+        assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits), (it, W, H, q, ss, kind)
+        if it % 3 == 0:
+            assert enc.encode_jfif(rgb, flags | jpeg.F_RESTART) == ol.oracle_std_jfif_restart(rgb, ql, qc, ss, 64), \
+                (it, W, H, q, ss, kind)
+    enc.set_quality(50)
