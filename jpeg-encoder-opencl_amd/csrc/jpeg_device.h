@@ -55,8 +55,6 @@ uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves);
 hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,
                                 bool probe, uint32_t grid_waves, hipStream_t s);
 hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams& sp, hipStream_t s);
-hipError_t launch_meta_sizes(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* lut,
-                             uint32_t* unit_off, uint32_t* tile_bits, uint32_t* status, hipStream_t s);
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,
                         const uint32_t* lut, const uint64_t* tile_off,
                         uint8_t* out, uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,

@@ -269,108 +269,6 @@ __device__ __forceinline__ void generic_chroma420(const uint8_t* __restrict__ f,
 // ----------------------------------------------------------------------------
 // (ScreenParams is declared in jpeg_device.h)
 
-struct SlotWriter {  // AC bits of one unit, word w at slot[w * stride]
-    uint32_t* slot;
-    uint32_t cap;     // words available
-    uint32_t stride;  // 64: an LDS slot in [word][lane] layout; 1: a run in memory
-    uint64_t acc;
-    uint32_t n;       // pending bits (< 32)
-    uint32_t w;       // words written
-    uint32_t bits;    // total bits
-    __device__ __forceinline__ void put(uint32_t code, uint32_t len) {
-        acc = (acc << len) | code;
-        n += len;
-        bits += len;
-        if (n >= 32) {
-            n -= 32;
-            if (w < cap) slot[w * stride] = (uint32_t)(acc >> n);
-            ++w;
-            acc &= (1ull << n) - 1;
-        }
-    }
-    __device__ __forceinline__ void flush() {
-        if (n) {
-            if (w < cap) slot[w * stride] = (uint32_t)(acc << (32 - n));
-            ++w;
-        }
-    }
-};
-
-// Branch-free bit writer into the lane's LDS slot ([word][lane] layout).  Pending bits are
-// kept left-aligned in a 64-bit accumulator; every put stores the current top word (a
-// later put to the same word overwrites it), so no flush branch and no final flush.
-struct SlotWriterBF {
-    uint32_t* wp;    // address of the word being filled
-    uint64_t acc;    // pending bits, left-aligned
-    uint32_t rem;    // 64 - pending count, in (32, 64]
-    uint32_t w;      // completed words
-    // t = 0 is a no-op provided m == 0; m < 2^t, t <= 31
-    __device__ __forceinline__ void put(uint32_t m, uint32_t t) {
-        rem -= t;
-        acc |= (uint64_t)m << rem;
-        *wp = (uint32_t)(acc >> 32);
-        const bool adv = rem <= 32;
-        acc = adv ? acc << 32 : acc;
-        rem = adv ? rem + 32 : rem;
-        w = adv ? w + 1 : w;
-        wp = adv ? wp + 64 : wp;
-    }
-    // a put that completes a word leaves the remainder unstored until the next put
-    __device__ __forceinline__ void finish() { *wp = (uint32_t)(acc >> 32); }
-    __device__ __forceinline__ uint32_t bits() const { return w * 32 + (64 - rem); }
-    __device__ __forceinline__ uint32_t words() const { return w + (rem < 64 ? 1u : 0u); }
-};
-
-// The unit walk of walk_ac(), restructured for the fused kernel: positions are handled
-// in groups of kWalkGroup; a first pass forms every LUT index (runs only need the zero/non-zero
-// pattern) and issues all LDS lookups, a second pass assembles and appends the symbols
-// without branches (zero coefficients append nothing).  Only the ZRL prefix of a run
-// >= 16 takes a (rare) divergent branch.  Same bits as walk_ac().
-constexpr int kWalkGroup = 8;
-__device__ __forceinline__ bool walk_ac_batched(const uint32_t (&c)[32], const uint32_t* __restrict__ act,
-                                                SlotWriterBF& bw) {
-    bool ok = true;
-    uint32_t run = 0;
-    const uint32_t zrl = act[0xF0], eob = act[0x00];
-#pragma unroll
-    for (int k0 = 1; k0 < 64; k0 += kWalkGroup) {
-        int v[kWalkGroup];
-        uint32_t e[kWalkGroup], sz[kWalkGroup], zc[kWalkGroup];
-#pragma unroll
-        for (int i = 0; i < kWalkGroup; ++i) {
-            const int k = k0 + i;
-            if (k > 63) break;
-            v[i] = (int)(int16_t)((k & 1) ? (c[k >> 1] >> 16) : (c[k >> 1] & 0xffffu));
-            const uint32_t a = (uint32_t)(v[i] < 0 ? -v[i] : v[i]);
-            sz[i] = 32u - (uint32_t)__clz((int)a);
-            const bool nz = v[i] != 0;
-            ok = ok && !(nz && sz[i] > 10u);
-            zc[i] = nz ? (run >> 4) : 0u;
-            e[i] = act[((run & 15u) << 4) | (sz[i] & 15u)];
-            run = nz ? 0u : run + 1u;
-        }
-#pragma unroll
-        for (int i = 0; i < kWalkGroup; ++i) {
-            const int k = k0 + i;
-            if (k > 63) break;
-            const bool nz = v[i] != 0;
-            if (k >= 17 && zc[i]) {  // (15,0) at every 16th zero before a later non-zero
-                for (uint32_t z = 0; z < zc[i]; ++z) bw.put(lut_code(zrl), lut_len(zrl));
-            }
-            const uint32_t len = lut_len(e[i]);
-            ok = ok && !(nz && len == 0u && sz[i] <= 10u);
-            const uint32_t vb = (uint32_t)(v[i] + ((v[i] >> 31) & ((1 << sz[i]) - 1)));
-            const uint32_t m = nz ? ((lut_code(e[i]) << sz[i]) | vb) : 0u;
-            const uint32_t t = nz ? len + sz[i] : 0u;
-            bw.put(m, t & 31u);
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: bounded register pressure
-    }
-    bw.put(lut_code(eob), lut_len(eob));  // ALWAYS (quirk Q8)
-    bw.finish();
-    return ok;
-}
-
 __device__ __forceinline__ int meta_dc(uint32_t y) { return (int)(int16_t)(y & 0xffffu); }
 
 // Arena allocation for one wave.  Every persistent wave owns a private region and bumps a
@@ -1084,7 +982,7 @@ __global__ void __launch_bounds__(256, 2)
 // k_dc_heads: DC symbol of the first unit of every (tile, pass).  Its predecessor is the last
 // block of the previous tile (or luma quarter-tile), encoded by another wave of k_screen_encode,
 // which therefore left the symbol out of the tile sum.  Every DC in `meta` is exact already
-// (fix-ups rewrite the same value).  Light on purpose (few registers, 128 B of LDS): it runs every
+// (the exact recomputation keeps coefficient 0).  Light on purpose (few registers, 128 B of LDS): it runs every
 // frame next to another stream's k_screen_encode.
 // ----------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
@@ -1122,8 +1020,7 @@ __global__ void __launch_bounds__(64)
 }
 
 // ----------------------------------------------------------------------------
-// k_meta_sizes: workgroup = tile (wave = channel, lane = block): total bits per
-// unit = DC symbol + AC string; tile-local exclusive offsets + tile sums.
+// DC predictor of a unit from `meta`: the previous lane, or the last block of the previous tile.
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ int meta_pred(const uint2* __restrict__ meta, size_t frame_tile0, uint32_t tile,
                                          uint32_t chan, uint32_t lane, int own_dc) {
@@ -1133,44 +1030,6 @@ __device__ __forceinline__ int meta_pred(const uint2* __restrict__ meta, size_t 
         if (tile > 0) prev = meta_dc(meta[((frame_tile0 + tile - 1) * 3 + chan) * 64 + 63].y);
     }
     return prev;
-}
-
-__global__ void __launch_bounds__(192)
-    k_meta_sizes(Geom g, const uint2* __restrict__ meta, const uint32_t* __restrict__ lut,
-                 uint32_t* __restrict__ unit_off, uint32_t* __restrict__ tile_bits,
-                 uint32_t* __restrict__ status) {
-    __shared__ uint32_t s_dc[2][16];
-    __shared__ uint32_t s_bits[192];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
-    const uint32_t tile = blockIdx.x, frame = blockIdx.y;
-    if (tid < 32) s_dc[tid >> 4][tid & 15] = lut[(tid >> 4) * 256 + (tid & 15)];
-    __syncthreads();
-    const size_t ft0 = (size_t)frame * g.tiles;
-    const uint2 m = meta[((ft0 + tile) * 3 + chan) * 64 + lane];
-    const int dc = meta_dc(m.y);
-    const int pred = meta_pred(meta, ft0, tile, chan, lane, dc);
-    const bool active = tile * 64 + lane < g.N;
-    uint32_t bits = m.y >> 16;
-    auto count = [&](uint32_t, uint32_t len) { bits += len; };
-    bool ok = put_dc(dc - pred, s_dc[chan ? 1 : 0], count);
-    if (!active) {
-        bits = 0;
-        ok = true;
-    }
-    if (!ok) atomicOr(status, 1u);
-    s_bits[lane * 3 + chan] = bits;
-    __syncthreads();
-    if (tid < 64) {
-        uint32_t a0 = s_bits[tid * 3], a1 = s_bits[tid * 3 + 1], a2 = s_bits[tid * 3 + 2];
-        uint32_t blk = a0 + a1 + a2;
-        uint32_t incl = wave_incl_scan(blk, tid);
-        uint32_t excl = incl - blk;
-        uint32_t* uo = unit_off + (ft0 + tile) * 192 + tid * 3;
-        uo[0] = excl;
-        uo[1] = excl + a0;
-        uo[2] = excl + a0 + a1;
-        if (tid == 63) tile_bits[ft0 + tile] = incl;
-    }
 }
 
 // ----------------------------------------------------------------------------
@@ -1353,12 +1212,6 @@ hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams&
     const uint64_t heads = (uint64_t)n_frames * g.tiles * g.passes;
     const uint32_t head_waves = (uint32_t)((heads + 63) / 64 < 4096 ? (heads + 63) / 64 : 4096);
     hipLaunchKernelGGL(k_dc_heads, dim3(head_waves), dim3(64), 0, s, g, n_frames, sp);
-    return hipGetLastError();
-}
-hipError_t launch_meta_sizes(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* lut,
-                             uint32_t* unit_off, uint32_t* tile_bits, uint32_t* status, hipStream_t s) {
-    hipLaunchKernelGGL(k_meta_sizes, dim3(g.tiles, n_frames), dim3(192), 0, s, g, meta, lut, unit_off,
-                       tile_bits, status);
     return hipGetLastError();
 }
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,

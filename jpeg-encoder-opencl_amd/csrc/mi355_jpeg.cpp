@@ -141,14 +141,14 @@ struct mi355_jpeg_ctx {
     double* d_qconst = nullptr;     // [2][64][4] accept thresholds for the current tables
     float* d_qconst_f = nullptr;    // [2][16][8] fp32 first-look scale factors and thresholds
     uint32_t* d_lut2 = nullptr;     // [2 modes][2][16][64] whole AC symbols for |value| <= 31
-    uint32_t* d_counters = nullptr; // [0] arena words, [1] fix-up list length
+    uint32_t* d_counters = nullptr; // [0] arena overflow-pool words ([1] unused)
     uint2* d_meta = nullptr;
     size_t meta_cap = 0;
     uint32_t* d_arena = nullptr;
     size_t arena_cap = 0;           // words
-    double tau_scale = 1.0;         // debug: widen the accept margins to force fix-ups
+    double tau_scale = 1.0;         // debug: widen the accept margins to force the exact recomputation
     uint32_t screen_waves = 2048;   // persistent single-wave workgroups of k_screen_encode
-    int transform_mode = 2;         // 0 exact fp64 chain (unrolled), 1 exact (looped), 2 screened MFMA + exact fix-up
+    int transform_mode = 2;         // 0 exact fp64 chain (unrolled), 1 exact (looped), 2 screened MFMA + exact recomputation of undecided units
     uint32_t emit_lds_words = 4096;
     uint32_t* d_stuff_counts = nullptr;  // byte stuffing scratch
     size_t stuff_cap = 0;

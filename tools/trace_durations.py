@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Development helper: mean/max duration per kernel in the multi-stream part of a rocprofv3
+--kernel-trace csv (argument: the -d output directory).  Used for DESIGN.md §4.5."""
 import csv,glob,collections,sys
 f=glob.glob(sys.argv[1]+'/*/*kernel_trace.csv')[0]
 rows=list(csv.DictReader(open(f)))
