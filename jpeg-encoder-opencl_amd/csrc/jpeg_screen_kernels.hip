@@ -717,8 +717,11 @@ __global__ void __launch_bounds__(256, 2)
         // issue slots and finish ~20 % later than the others (measured with in-kernel timestamps:
         // mean wave end 41.5 vs 49.3 us), leaving the SIMDs half empty at the end.  Raising their
         // priority outside the (LDS-latency-bound) entropy walk equalises the two halves
-        // (45.9 vs 45.4 us) and shortens the kernel by 8 %.  Speed only.
-        if (blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(1);
+        // (45.9 vs 45.4 us) and shortens the kernel by 8 %.  Only when this launch fills the device with
+        // exactly two workgroups per CU (sp.prio_from_wg = number of CUs, else none): half-device launches
+        // of pipelined callers share each CU with another stream's kernel and do better without it (+3 %).
+        // Speed only.
+        if (blockIdx.x >= sp.prio_from_wg) __builtin_amdgcn_s_setprio(1);
 
         s_mlo[lane] = 0;
         s_mhi[lane] = 0;

@@ -112,6 +112,7 @@ struct EventSet {
 
 struct mi355_jpeg_ctx {
     int device = 0;
+    int n_cus = 0;  // compute units of the device
     uint32_t qlum[64], qchrom[64];
     mi355_huff_table huff[4];
     mi355_huff_table huff_std[4];  // standard mode (MI355_F_STANDARD): Annex K proper unless the caller set a table
@@ -350,6 +351,8 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
                            uint32_t* coefs) {
     ScreenParams sp;
     const size_t arena_words = plan.total_words;
+    // the later-dispatched half of a launch that fills the device two workgroups per CU (see the kernel)
+    sp.prio_from_wg = (c->n_cus > 0 && plan.grid / 4 == 2u * (uint32_t)c->n_cus) ? (uint32_t)c->n_cus : 0xFFFFFFFFu;
     sp.region_words = plan.region_words;
     sp.overflow_base = plan.grid * plan.region_words;
     const bool stdm = (g.flags & MI355_F_STANDARD) != 0;
@@ -521,6 +524,11 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     mi355_jpeg_ctx* c = new (std::nothrow) mi355_jpeg_ctx();
     if (!c) return MI355_E_ALLOC;
     c->device = device_id;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess) c->n_cus = cus;
+        if (c->n_cus > 0) c->screen_waves = 8u * (uint32_t)c->n_cus;  // two 4-wave workgroups per CU (2048 on MI355X)
+    }
     for (int i = 0; i < 64; ++i) c->qlum[i] = kQ50Lum[i], c->qchrom[i] = kQ50Chr[i];
     for (int t = 0; t < 4; ++t) reference_huffman(t, &c->huff[t]), reference_huffman(t, &c->huff_std[t], false);
     const char* m = getenv("MI355_JPEG_TRANSFORM_MODE");
@@ -613,7 +621,7 @@ int mi355_jpeg_set_huffman(mi355_jpeg_ctx* c, int table, const mi355_huff_table*
 
 int mi355_jpeg_set_encode_waves(mi355_jpeg_ctx* c, uint32_t waves) {
     if (!c || (waves != 0 && (waves < 32 || waves > 8192 || (waves & 31)))) return MI355_E_ARG;
-    c->screen_waves = waves ? waves : 2048;
+    c->screen_waves = waves ? waves : (c->n_cus > 0 ? 8u * (uint32_t)c->n_cus : 2048u);
     return MI355_OK;
 }
 
