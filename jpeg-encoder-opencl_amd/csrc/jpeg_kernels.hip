@@ -174,24 +174,27 @@ __global__ void __launch_bounds__(192)
 }
 
 // ----------------------------------------------------------------------------
-// k_tile_scan: one 1024-thread workgroup per frame; exclusive 64-bit scan of the tile
-// sums (each thread owns a contiguous chunk of tiles).  Also zeroes every output word
-// that two tiles share (the emit/merge kernels OR into those), writes the frame's bit
-// count, checks the caller's capacity and -- for the screened pipeline, whose encode
-// kernel accumulates the tile sums with atomics -- re-arms the sums and counters.
+// k_tile_scan: one workgroup per frame (NT = 256 threads, 1024 for frames with many tiles);
+// exclusive 64-bit scan of the tile sums (each thread owns a contiguous chunk of tiles).  Also zeroes
+// every output word that two tiles share (the emit/merge kernels OR into those), writes the frame's bit
+// count, checks the caller's capacity and -- for the screened pipeline, whose encode kernel
+// accumulates the tile sums with atomics -- re-arms the sums and counters.  The 256-thread form is
+// one wave per SIMD with few registers: it fits on a CU next to two resident workgroups of
+// k_screen_encode of another stream (a 1024-thread workgroup has to wait for a free slot).
 // ----------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
+template <uint32_t NT>
+__global__ void __launch_bounds__(NT)
     k_tile_scan(Geom g, uint32_t* __restrict__ tile_bits, uint64_t* __restrict__ tile_off,
                 uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ frame_bits,
                 uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters, uint32_t rearm_tiles) {
-    __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_wave[NT / 64];
     __builtin_amdgcn_s_setprio(3);  // short, on the stream's critical path, resident next to encode kernels
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t frame = blockIdx.x;
     uint32_t* tb = tile_bits + (size_t)frame * g.tiles;
     uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
     uint32_t* outw = reinterpret_cast<uint32_t*>(out + (size_t)frame * out_stride);
-    const uint32_t per = (g.tiles + 1023u) / 1024u;
+    const uint32_t per = (g.tiles + NT - 1u) / NT;
     const uint32_t lo = tid * per < g.tiles ? tid * per : g.tiles;
     const uint32_t hi = lo + per < g.tiles ? lo + per : g.tiles;
     // restart intervals (standard mode, MI355_F_RESTART): every tile starts on a byte boundary
@@ -216,7 +219,7 @@ __global__ void __launch_bounds__(1024)
         run += (tb[i] + pad) & ~pad;
         if (rearm_tiles) tb[i] = 0;
     }
-    if (tid == 1023) {
+    if (tid == NT - 1) {
         const uint64_t total = pre + incl;
         to[g.tiles] = total;
         frame_bits[frame] = total;
@@ -382,8 +385,12 @@ hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, uint32_t* tile_bit
                             uint64_t* tile_off, uint8_t* out, uint64_t out_stride,
                             uint64_t* frame_bits, uint32_t* status, uint32_t* reset_counters,
                             bool rearm_tiles, hipStream_t s) {
-    hipLaunchKernelGGL(k_tile_scan, dim3(n_frames), dim3(1024), 0, s, g, tile_bits, tile_off, out,
-                       out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u);
+    if (g.tiles <= 8192)
+        hipLaunchKernelGGL(k_tile_scan<256>, dim3(n_frames), dim3(256), 0, s, g, tile_bits, tile_off, out,
+                           out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u);
+    else
+        hipLaunchKernelGGL(k_tile_scan<1024>, dim3(n_frames), dim3(1024), 0, s, g, tile_bits, tile_off, out,
+                           out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u);
     return hipGetLastError();
 }
 hipError_t launch_emit(const Geom& g, uint32_t n_frames, const uint32_t* coefs, const uint32_t* lut,

@@ -182,7 +182,11 @@ int ensure(T*& p, size_t& cap, size_t need, bool zero = false) {
     p = nullptr;
     cap = 0;
     if (hipMalloc((void**)&p, need * sizeof(T)) != hipSuccess) return MI355_E_ALLOC;
-    if (zero && hipMemset(p, 0, need * sizeof(T)) != hipSuccess) return MI355_E_ALLOC;
+    // The fill runs on the null stream and may still be in flight when hipMemset returns; the caller's
+    // stream is usually non-blocking (no implicit ordering with the null stream): wait for it here, or
+    // the first kernel could add into accumulators that are zeroed afterwards.
+    if (zero && (hipMemset(p, 0, need * sizeof(T)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess))
+        return MI355_E_ALLOC;
     cap = need;
     return MI355_OK;
 }
@@ -268,6 +272,9 @@ int upload_tables(mi355_jpeg_ctx* c) {
             L[0] = entry(t.code[0x00], t.len[0x00]);            // EOB likewise; column 32 (value 0) stays 0
         }
     HIP_TRY(hipMemcpy(c->d_lut2, lut2.data(), lut2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // copies from pageable memory may return before the DMA has landed; encode calls run on
+    // non-blocking streams that do not order themselves after the null stream
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return MI355_OK;
 }
 
@@ -554,6 +561,7 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     if (!e) e = hip_err(hipMemset(c->d_counters, 0, 2 * sizeof(uint32_t)));
     if (!e) e = upload_afrag(c);
     if (!e) e = upload_tables(c);
+    if (!e) e = hip_err(hipDeviceSynchronize());  // every fill and table copy above has landed
     if (e) {
         mi355_jpeg_destroy(c);
         return e;
@@ -744,7 +752,10 @@ int mi355_jpeg_sync(mi355_jpeg_ctx* c, void* stream) {
 #endif
     uint32_t st = 0;
     HIP_TRY(hipMemcpy(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost));
-    if (st) HIP_TRY(hipMemset(c->d_status, 0, sizeof st));
+    if (st) {
+        HIP_TRY(hipMemset(c->d_status, 0, sizeof st));
+        HIP_TRY(hipStreamSynchronize(nullptr));  // the clear has landed before the next call's kernels look
+    }
     return status_to_error(st);
 }
 
