@@ -552,6 +552,31 @@ def test_pipelined_contexts_share_the_device(jpeg):
         e.close()
 
 
+def test_first_call_of_a_fresh_context_on_a_nonblocking_stream(jpeg):
+    """Regression: workspace fills and table copies issued on the null stream at (re)allocation must have
+    landed before the first kernels run on the caller's non-blocking stream (they once could zero the
+    tile accumulators after the block-encode kernel had added to them -> short scans, rarely)."""
+    import torch
+    W, H = 1280, 720
+    rgb = ol.lcg_frame(W, H, 5)
+    want = ol.oracle_encode(rgb)
+    dev = torch.device("cuda", 0)
+    d_rgb = torch.from_numpy(rgb).to(dev)
+    cap = 2 << 20
+    for rep in range(12):
+        e2 = jpeg.Encoder(0)
+        st = torch.cuda.Stream(device=dev)
+        d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        d_bits = torch.zeros(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        e2.encode_scan_device(d_rgb.data_ptr(), W, H, 1, d_out.data_ptr(), cap, d_bits.data_ptr(), stream=st.cuda_stream)
+        e2.sync(st.cuda_stream)
+        nb = int(d_bits[0])
+        assert nb == want.n_bits, rep
+        assert np.array_equal(d_out[:(nb + 7) // 8].cpu().numpy(), want.bits), rep
+        e2.close()
+
+
 def test_two_contexts_two_threads(jpeg):
     """Contexts are independent: two host threads, each with its own context and stream on
     the same GPU, encode different batches concurrently."""
