@@ -1049,12 +1049,16 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
             uint32_t lds_words_limit) {
     constexpr uint32_t NT = S420 ? 384 : 192, UPB = S420 ? 6 : 3;  // threads, units per scan step (block / MCU)
     __builtin_amdgcn_s_setprio(3);  // see k_dc_heads
+    // the 4:2:0 form gives up 256 window words for its longer offset array, so that both forms stay
+    // within the 17.9 KiB a CU has left next to two resident workgroups of k_screen_encode
+    constexpr uint32_t kWindow = S420 ? kEmitLdsWords - 256 : kEmitLdsWords;
     __shared__ uint32_t s_dc[2][16];
     __shared__ uint32_t s_bits[NT];
-    __shared__ uint32_t s_words[kEmitLdsWords];
+    __shared__ uint32_t s_words[kWindow];
     const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
     const uint32_t tile = blockIdx.x, frame = blockIdx.y;
     if (*status) return;
+    if (lds_words_limit > kWindow) lds_words_limit = kWindow;
     const size_t ft0 = (size_t)frame * g.tiles;
     const uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
     const uint64_t start = to[tile], end = to[tile + 1];
