@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(NT)
         frame_bits[frame] = total;
         if (((total + 31) >> 5) * 4 > out_stride) atomicOr(status, 2u);  // MI355_E_CAPACITY
         // the screened pipeline's arena counter is consumed by now: re-arm it
-        if (reset_counters && frame == 0) reset_counters[0] = 0, reset_counters[1] = 0;
+        if (reset_counters && frame == 0) reset_counters[0] = 0;
     }
 }
 

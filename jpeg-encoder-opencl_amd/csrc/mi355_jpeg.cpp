@@ -113,6 +113,11 @@ struct EventSet {
 struct mi355_jpeg_ctx {
     int device = 0;
     int n_cus = 0;  // compute units of the device
+    // batches are encoded as two halves: the tail kernels of the first half run on `side` under the
+    // block-encode kernel of the second half
+    hipStream_t side = nullptr;
+    hipEvent_t ev_half = nullptr, ev_side = nullptr;
+    uint32_t batch_parts = 8;  // MI355_JPEG_BATCH_PARTS: upper limit of the parts of a batch (1 = off, at most 8)
     uint32_t qlum[64], qchrom[64];
     mi355_huff_table huff[4];
     mi355_huff_table huff_std[4];  // standard mode (MI355_F_STANDARD): Annex K proper unless the caller set a table
@@ -445,29 +450,98 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
     return MI355_OK;
 }
 
+// One part of a batch: frames [f0, f0 + nf) with their slices of the workspace; `arena0` = first arena
+// word of this part, `counter` = its overflow-pool pointer.
+constexpr uint32_t kMaxParts = 8;
+struct BatchPart {
+    uint32_t f0, nf;
+    ArenaPlan plan;
+    size_t arena0;
+    uint32_t counter;
+};
+
+ScreenParams part_params(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p) {
+    ScreenParams sp = screen_params(c, g, p.nf, p.plan, nullptr);
+    sp.meta = c->d_meta + (size_t)p.f0 * g.tiles * g.passes * 64;
+    sp.arena = c->d_arena + p.arena0;
+    sp.counters = c->d_counters + p.counter;
+    sp.tile_bits = c->d_tile_bits + (size_t)p.f0 * g.tiles;
+    return sp;
+}
+
+int launch_tails(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p, const ScreenParams& sp, uint8_t* d_out,
+                 size_t out_stride, uint64_t* d_bits, hipStream_t s, bool rec) {
+    HIP_TRY(launch_dc_heads(g, p.nf, sp, s));
+    if (rec) record(c, 2, s);  // slot [1,2] = DC heads (the other tile sums are accumulated by the encode kernel itself)
+    HIP_TRY(launch_tile_scan(g, p.nf, sp.tile_bits, c->d_tile_off + (size_t)p.f0 * (g.tiles + 1),
+                             d_out + (size_t)p.f0 * out_stride, out_stride, d_bits + p.f0, c->d_status, sp.counters,
+                             true, s));
+    if (rec) record(c, 3, s);
+    HIP_TRY(launch_merge(g, p.nf, sp.meta, sp.arena, sp.lut, c->d_tile_off + (size_t)p.f0 * (g.tiles + 1),
+                         d_out + (size_t)p.f0 * out_stride, out_stride, c->d_status, c->emit_lds_words, s));
+    if (rec) record(c, 4, s);
+    return MI355_OK;
+}
+
 // Screened pipeline: k_screen_encode -> k_dc_heads -> k_tile_scan -> k_merge.
 // Event slots: [0,1] fused block encode (transform_ms), [1,2] DC heads (size_ms), [2,3] scan, [3,4] merge (emit_ms).
+// Batches of four or more frames go in parts: the tail kernels of a part run on a side stream under the
+// block-encode kernel of the next part (they fit next to its resident workgroups); with
+// per-stage profiling on, one part, so that the stage times stay meaningful.
 int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t* d_rgb, uint8_t* d_out,
                  size_t out_stride, uint64_t* d_bits, hipStream_t s) {
-    // AC blobs are word aligned per unit: at most total_bits/32 + one word per unit
-    // AC strings are word aligned per unit (<= bits/32 + 1 words); strings longer than the LDS
-    // slot (24 words) get a full 54-word run, i.e. at most 54/24 of their own size
-    ArenaPlan plan = plan_arena(c, g, n_frames, (size_t)n_frames * (out_stride / 4 * 9 / 4 + unit_count(g) + 64));
-    if (plan.total_words > 0xFFFFFFFFull) return MI355_E_ARG;  // 32-bit word offsets: split the batch
+    // parts: at least two frames and ~64 Mpixel (~0.4 ms of block encode) each -- every part pays the ramp and
+    // tail of one more launch -- at most batch_parts (8)
+    uint32_t nparts = 1;
+    if (n_frames >= 4 && c->profiling != 1) {
+        const uint64_t px = (uint64_t)n_frames * g.W * g.H;
+        nparts = (uint32_t)(px >> 26);
+        if (nparts > n_frames / 2) nparts = n_frames / 2;
+        if (nparts > c->batch_parts) nparts = c->batch_parts;
+        if (nparts < 1) nparts = 1;
+    }
+    BatchPart part[kMaxParts];
+    size_t arena_words = 0;
+    for (uint32_t i = 0, f = 0; i < nparts; ++i) {
+        part[i].f0 = f;
+        part[i].nf = (uint32_t)(((uint64_t)n_frames * (i + 1)) / nparts) - f;
+        f += part[i].nf;
+        // AC strings are word aligned per unit (<= bits/32 + 1 words); strings longer than the LDS
+        // slot (24 words) get a full 54-word run, i.e. at most 54/24 of their own size
+        part[i].plan = plan_arena(c, g, part[i].nf, (size_t)part[i].nf * (out_stride / 4 * 9 / 4 + unit_count(g) + 64));
+        part[i].arena0 = arena_words;
+        part[i].counter = i;
+        arena_words += part[i].plan.total_words;
+        if (arena_words > 0xFFFFFFFFull) return MI355_E_ARG;  // 32-bit word offsets: split the batch
+    }
     int e;
-    if ((e = ensure_screen_workspace(c, g, n_frames, plan.total_words))) return e;
-    ScreenParams sp = screen_params(c, g, n_frames, plan, nullptr);
+    if ((e = ensure_screen_workspace(c, g, n_frames, arena_words))) return e;
+    if (nparts > 1 && !c->side) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+    }
     record(c, 0, s);
-    HIP_TRY(launch_screen_encode(g, n_frames, d_rgb, sp, false, c->screen_waves, s));
-    record(c, 1, s);
-    HIP_TRY(launch_dc_heads(g, n_frames, sp, s));
-    record(c, 2, s);  // slot [1,2] = DC heads (the other tile sums are accumulated by the encode kernel itself)
-    HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
-                             c->d_status, c->d_counters, true, s));
-    record(c, 3, s);
-    HIP_TRY(launch_merge(g, n_frames, c->d_meta, c->d_arena, sp.lut, c->d_tile_off, d_out,
-                         out_stride, c->d_status, c->emit_lds_words, s));
-    record(c, 4, s);
+    for (uint32_t i = 0; i < nparts; ++i) {
+        const ScreenParams sp = part_params(c, g, part[i]);
+        HIP_TRY(launch_screen_encode(g, part[i].nf, d_rgb + (size_t)part[i].f0 * g.frame_stride, sp, false,
+                                     c->screen_waves, s));
+        if (i + 1 == nparts) {  // the last part's tails stay on the caller's stream
+            record(c, 1, s);
+            if ((e = launch_tails(c, g, part[i], sp, d_out, out_stride, d_bits, s, nparts == 1))) return e;
+        } else {  // tails on the side stream, under the next part's block encode
+            HIP_TRY(hipEventRecord(c->ev_half, s));
+            HIP_TRY(hipStreamWaitEvent(c->side, c->ev_half, 0));
+            if ((e = launch_tails(c, g, part[i], sp, d_out, out_stride, d_bits, c->side, false))) return e;
+        }
+    }
+    if (nparts > 1) {
+        HIP_TRY(hipEventRecord(c->ev_side, c->side));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_side, 0));
+        record(c, 2, s);
+        record(c, 3, s);
+        record(c, 4, s);
+    }
     return MI355_OK;
 }
 
@@ -544,6 +618,8 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     if (l) c->emit_lds_words = (uint32_t)atoi(l);
     const char* ts = getenv("MI355_JPEG_SCREEN_TAU_SCALE");
     if (ts) c->tau_scale = atof(ts);
+    const char* bp = getenv("MI355_JPEG_BATCH_PARTS");
+    if (bp && atoi(bp) >= 1 && atoi(bp) <= 8) c->batch_parts = (uint32_t)atoi(bp);
     const char* sw = getenv("MI355_JPEG_SCREEN_WAVES");
     if (sw && atoi(sw) > 0) c->screen_waves = (uint32_t)atoi(sw);
     int e = MI355_OK;
@@ -555,10 +631,10 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst_f, 256 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut2, 4096 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, 2 * sizeof(uint32_t)) != hipSuccess)
+        hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) != hipSuccess)
         e = MI355_E_ALLOC;
     if (!e) e = hip_err(hipMemset(c->d_status, 0, sizeof(uint32_t)));
-    if (!e) e = hip_err(hipMemset(c->d_counters, 0, 2 * sizeof(uint32_t)));
+    if (!e) e = hip_err(hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t)));
     if (!e) e = upload_afrag(c);
     if (!e) e = upload_tables(c);
     if (!e) e = hip_err(hipDeviceSynchronize());  // every fill and table copy above has landed
@@ -573,6 +649,9 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
 void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_half) (void)hipEventDestroy(c->ev_half);
+    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
     void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
                     c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
                     c->d_counters, c->d_meta,     c->d_arena,  c->d_lut2,     c->d_qconst_f,
