@@ -421,8 +421,7 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
                                               const uint32_t* __restrict__ act, Packer32<Store>& pk,
                                               const uint32_t maxcnt) {
     uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
-    uint32_t prev = 0;
-    bool ok = true;
+    uint32_t prev = 0, coded = 0;
 
     auto stageA = [&]() -> WalkA {
         WalkA a;
@@ -453,7 +452,7 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
     auto stageC = [&](const WalkB& b) {
         uint32_t e = b.e_fast;
         if (!b.fast) e = symbol_slow(b.v, b.r, act);
-        ok = ok && !(b.v != 0 && e == 0u);
+        coded += e != 0u ? 1u : 0u;  // every non-zero coefficient must find a code (checked after the loop)
         if (b.zc) {  // (15,0) at every 16th zero before a later non-zero
             const uint32_t z = lut2[kLut2Zrl];
             for (uint32_t i = 0; i < b.zc; ++i) pk.put(z);
@@ -489,7 +488,7 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
     // the reference appends EOB ALWAYS (quirk Q8); a standard encoder omits it after coefficient 63
     if (!(STD && (mask >> 63))) pk.put(lut2[kLut2Eob]);
     pk.finish();
-    return ok;
+    return coded == (uint32_t)__popcll(mask);  // false: a size category without a code (quirk Q13)
 }
 
 // ----------------------------------------------------------------------------
