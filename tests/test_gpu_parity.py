@@ -577,6 +577,47 @@ def test_first_call_of_a_fresh_context_on_a_nonblocking_stream(jpeg):
         e2.close()
 
 
+@pytest.mark.parametrize("W,H", [(65528, 8), (8, 65528), (65535, 9), (24, 4099)])
+def test_extreme_aspect_ratios(jpeg, enc, W, H):
+    """Maximum width / height (one row or one column of blocks; the last column / row mirror-padded)."""
+    rgb = ol.lcg_frame(W, H, 11)
+    set_quality(enc, 50)
+    o = ol.oracle_encode(rgb)
+    bits, nb = enc.encode_scan(rgb)
+    assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits)
+    ql, qc = ol.quant_tables(50)
+    for ss in (0, 1):
+        w = ol.oracle_std_encode(rgb, ql, qc, subsample=ss)
+        bits, nb = enc.encode_scan(rgb, jpeg.F_STANDARD | (jpeg.F_420 if ss else 0))
+        assert nb[0] == w.n_bits and np.array_equal(bits[0], w.bits), ss
+
+
+def test_many_tiny_frames_and_unaligned_device_pointer(jpeg, enc):
+    """1000 one-block frames in one call; and a device buffer that starts one byte off an 8-byte
+    boundary (the kernel then takes its byte-wise row loader)."""
+    import torch
+    set_quality(enc, 50)
+    rng = np.random.default_rng(7)
+    frames = rng.integers(0, 256, (1000, 8, 8, 3), dtype=np.uint8)
+    bits, nb = enc.encode_scan(frames, cap=256)
+    for f in (0, 1, 499, 999):
+        o = ol.oracle_encode(frames[f])
+        assert nb[f] == o.n_bits and np.array_equal(bits[f], o.bits), f
+    W, H = 640, 360
+    rgb = ol.lcg_frame(W, H, 21)
+    want = ol.oracle_encode(rgb)
+    dev = torch.device("cuda", 0)
+    buf = torch.zeros(W * H * 3 + 16, dtype=torch.uint8, device=dev)
+    buf[1:1 + W * H * 3] = torch.from_numpy(rgb.reshape(-1)).to(dev)
+    d_out = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    d_bits = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    enc.encode_scan_device(buf.data_ptr() + 1, W, H, 1, d_out.data_ptr(), 1 << 20, d_bits.data_ptr())
+    enc.sync()
+    n = int(d_bits[0])
+    assert n == want.n_bits and np.array_equal(d_out[:(n + 7) // 8].cpu().numpy(), want.bits)
+
+
 def test_two_contexts_two_threads(jpeg):
     """Contexts are independent: two host threads, each with its own context and stream on
     the same GPU, encode different batches concurrently."""
