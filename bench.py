@@ -153,6 +153,27 @@ def cpu_baseline():
     }
 
 
+def cpu_baseline_multicore(max_threads=16):
+    """The generous version of the CPU baseline: one 4K frame per host thread, all threads at
+    once (the reference itself is single-threaded; ctypes releases the GIL inside the C call)."""
+    import concurrent.futures
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    n = max(1, min(max_threads, os.cpu_count() or 1))
+    rgb = ol.lcg_frame(W, H, 1)
+    ql, qc = ol.quant_tables(QUALITY)
+    use_ref = ol.ref() is not None
+    fn = (lambda: ol.ref_encode(rgb, ql, qc, True).n_bits) if use_ref else (lambda: ol.oracle_encode(rgb, ql, qc, True).n_bits)
+    t0 = time.perf_counter()
+    with concurrent.futures.ThreadPoolExecutor(n) as ex:
+        bits = list(ex.map(lambda _: fn(), range(n)))
+    dt = time.perf_counter() - t0
+    assert all(b == GOLDEN_SEED1_BITS for b in bits)
+    return {"value": round(n * W * H / dt / 1e6, 4), "unit": "Mpixel/s", "cores": n,
+            "kind": "reference" if use_ref else "port",
+            "sample": "%d frames 3840x2160 (LCG seed 1), one per host thread, %.2f s wall" % (n, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,6 +331,10 @@ def main():
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            try:  # extra, never the reported baseline: all host threads at once
+                line["cpu_baseline_all_threads"] = cpu_baseline_multicore()
+            except Exception as exc:  # pragma: no cover
+                line["cpu_baseline_all_threads"] = {"error": str(exc)}
         print(json.dumps(line), flush=True)
 
     for e in encs:
