@@ -185,6 +185,7 @@ def main():
                          "tail kernels of one frame overlap the block-encode kernel of the next")
     ap.add_argument("--encode-waves", type=int, default=1024,
                     help="persistent waves of the block-encode kernel per call when --streams > 1 (0 = fill the device)")
+    ap.add_argument("--cap-mb", type=int, default=8, help="output capacity per frame slot in MiB")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -222,7 +223,7 @@ def main():
     d_rgb = torch.empty((R, H, W, 3), dtype=torch.uint8, device=dev)
     enc.synth_lcg_device(d_rgb.data_ptr(), W * H * 3, R, shard_seed0(rank, R))
     enc.sync()
-    cap = 8 << 20  # bytes per frame slot (noise at q50 needs 4.8 MB)
+    cap = args.cap_mb << 20  # bytes per frame slot (noise at q50 needs 4.8 MB)
     d_out = torch.zeros((R, cap), dtype=torch.uint8, device=dev)
     d_bits = torch.zeros(R, dtype=torch.int64, device=dev)
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
