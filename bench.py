@@ -319,6 +319,9 @@ def main():
                          "kernel": "k_screen_encode", "kernel_ms": round(t_kernel * 1e3, 5),
                          "kernel_ms_raw_bracket": round(raw_ms, 5), "empty_bracket_ms": round(bracket_ms, 5),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "kernel_ms_scope": "the kernel alone on the whole device (single-stream pass after the timed "
+                                            "region; rocprofv3 agrees on `bench.py --streams 1`); in the timed region "
+                                            "several such kernels share the device and last ~3x longer each",
                          "note": "bit-exact strict mode: the reference's order-dependent fp64 chain is evaluated "
                                  "as an exact integer-MFMA map + verification; the kernel is bound by VALU "
                                  "instruction issue (colour conversion, quantise+verify, entropy walk), not by "
