@@ -22,4 +22,4 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
         if (bits[f], h) != ref[key] or (key == 0 and bits[f] != 38227880):
             bad += 1
             print("rep", rep, "frame", f, "bits", bits[f], "expected", ref[key][0])
-print("lanes", os.environ.get("MI355_JPEG_BATCH_LANES"), "bad frames:", bad)
+print("batch parts limit", os.environ.get("MI355_JPEG_BATCH_PARTS", "default"), "- bad frames:", bad)
