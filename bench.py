@@ -294,13 +294,15 @@ def main():
         # HBM bytes per launch of the dominant kernel from the PMC passes committed under
         # profiles/ (FETCH_SIZE / WRITE_SIZE, separate passes, corrected as
         # MI355X_MICROARCH.md prescribes); null when no such measurement is committed.
-        traffic = None
+        traffic = valu_insts = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_screen_encode_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("k_screen_encode_hbm_bytes_per_launch")
+                valu_insts = tj.get("k_screen_encode_valu_insts_per_launch")
             except Exception:
-                traffic = None
+                traffic = valu_insts = None
         line = {
             "metric": "Mpixels/s encode (3840x2160 RGB, q=50)",
             "value": round(total_px / dt / 1e6, 2), "unit": "Mpixel/s",
@@ -333,6 +335,16 @@ def main():
                                                   "execute these ops, it replaces them",
                                           "algorithmic_ops_per_launch": units * ALG_FP64_OPS_PER_UNIT},
         }
+        if valu_insts:
+            # informational: what actually binds the kernel.  A CDNA4 SIMD is 32 lanes wide, a wave64 VALU
+            # instruction holds it for 2 cycles: peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 wave-instructions/s.
+            peak = 256 * 4 * 2.4e9 / 2 / 1e12
+            line["valu_issue"] = {"achieved": round(valu_insts / t_kernel / 1e12, 4), "peak": round(peak, 4),
+                                  "unit": "T wave-instructions/s", "frac": round(valu_insts / t_kernel / 1e12 / peak, 4),
+                                  "insts_per_launch": valu_insts,
+                                  "note": "SQ_INSTS_VALU from the committed PMC pass; two resident waves per SIMD "
+                                          "(216 VGPRs, 71 KiB LDS per workgroup), each can issue one VALU "
+                                          "instruction per 4 cycles at best: the occupancy-limited ceiling is frac 0.5"}
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             try:  # extra, never the reported baseline: all host threads at once
