@@ -343,8 +343,9 @@ def main():
                                   "unit": "T wave-instructions/s", "frac": round(valu_insts / t_kernel / 1e12 / peak, 4),
                                   "insts_per_launch": valu_insts,
                                   "note": "SQ_INSTS_VALU from the committed PMC pass; two resident waves per SIMD "
-                                          "(216 VGPRs, 71 KiB LDS per workgroup), each can issue one VALU "
-                                          "instruction per 4 cycles at best: the occupancy-limited ceiling is frac 0.5"}
+                                          "(216 VGPRs, 71 KiB LDS per workgroup), each can issue one VALU instruction "
+                                          "per 4 cycles at best, so they fill the SIMD only if neither ever waits; "
+                                          "each is VALU-active ~35 % of its cycles (DESIGN.md 4.4)"}
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             try:  # extra, never the reported baseline: all host threads at once
