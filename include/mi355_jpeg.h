@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MI355_JPEG_ABI_VERSION 1
+#define MI355_JPEG_ABI_VERSION 2
 
 typedef struct mi355_jpeg_ctx mi355_jpeg_ctx;
 
@@ -39,7 +39,9 @@ enum mi355_jpeg_status {
     MI355_E_CATEGORY = -4,   /* a DC size > 11 or AC size > 10: the reference reads past its tables
                                 (huffman.hpp:9-23,45-57) -- defined here as an error */
     MI355_E_ALLOC = -5,      /* device or host allocation failed */
-    MI355_E_TABLE = -6,      /* malformed quantisation / Huffman table */
+    MI355_E_TABLE = -6,      /* malformed quantisation / Huffman table; a container asked for with quantiser
+                                entries > 255 (an 8-bit DQT cannot hold them) */
+    MI355_E_INTERNAL = -7,   /* a device-side wait gave up (should never happen; results of the call are invalid) */
     MI355_E_HIP = -100       /* MI355_E_HIP - hipError_t */
 };
 
@@ -97,7 +99,11 @@ int mi355_jpeg_device_count(void);
 int mi355_jpeg_create(int device_id, mi355_jpeg_ctx **ctx);
 void mi355_jpeg_destroy(mi355_jpeg_ctx *ctx);
 
-/* ---- tables (utils.hpp:42-62, huffman.hpp) ---------------------------- */
+/* ---- tables (utils.hpp:42-62, huffman.hpp) ----------------------------
+ * The setters wait for the whole device (hipDeviceSynchronize) before they rewrite the device-resident
+ * tables, so encode calls still in flight on any stream finish with the tables they were issued under;
+ * calls issued afterwards see the new set.  (A context is single-owner: do not call a setter from one
+ * thread while another thread issues encode calls on the same context.) */
 /* qlum/qchrom: 64 entries, row-major [v][u] exactly like quant_mat_lum[8][8];
  * values 1..65535.  Replaces the table arguments of performQuantization
  * (utils.cpp:454). */
@@ -124,8 +130,12 @@ int mi355_jpeg_set_encode_waves(mi355_jpeg_ctx *ctx, uint32_t waves);
 
 /* ---- geometry helpers (getNearest8x8ImageSize, utils.cpp:184-187) ------ */
 void mi355_jpeg_padded_size(uint32_t W, uint32_t H, uint32_t *W8, uint32_t *H8);
-/* Upper bound in bytes of one frame's packed scan bits (what to size `out` as). */
+/* Upper bound in bytes of one frame's packed scan bits (what to size `out` as) in strict mode and
+ * standard 4:4:4 (flags without MI355_F_420 / MI355_F_RESTART). */
 size_t mi355_jpeg_scan_bound(uint32_t W, uint32_t H);
+/* The same for any flags: 4:2:0 pads to 16x16 MCUs of six units, restart intervals pad every interval
+ * to a byte boundary. */
+size_t mi355_jpeg_scan_bound_flags(uint32_t W, uint32_t H, uint32_t flags);
 
 /* ---- the hot path ------------------------------------------------------
  * rgb: interleaved 8-bit RGB, W*H*3 bytes per frame, row-major, frames
@@ -152,7 +162,9 @@ int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx *ctx, const void *d_rgb, uint32
                                   uint32_t n_frames, uint32_t flags, void *d_out,
                                   size_t out_stride, uint64_t *d_bits, void *stream);
 /* Waits for `stream`, then returns the first device-side error of the calls
- * issued since the previous sync (MI355_OK if none). */
+ * issued since the previous sync (MI355_OK if none).  After an error EVERYTHING issued on this
+ * context since the previous sync must be discarded: the outputs of those calls are undefined (frames
+ * after the failing one are not written at all). */
 int mi355_jpeg_sync(mi355_jpeg_ctx *ctx, void *stream);
 
 /* Whole file: build-defined JFIF framing (the reference writes no container,
@@ -231,6 +243,23 @@ int mi355_jpeg_last_timings(mi355_jpeg_ctx *ctx, mi355_jpeg_timings *t);
 /* Sums over all encode calls since profiling was enabled (waits for their
  * events); *calls receives the number of calls summed. */
 int mi355_jpeg_profile_summary(mi355_jpeg_ctx *ctx, mi355_jpeg_timings *sum, uint32_t *calls);
+
+/* Launch shape of the last encode call: how many launches of the block-encode kernel (the dominant
+ * kernel) it was split into.  bench.py divides the event bracket of a call by this. */
+int mi355_jpeg_last_call_launches(mi355_jpeg_ctx *ctx, uint32_t *block_encode_launches);
+
+/* How often the screened transform had to look twice, since the context was created
+ * or the counters were last reset.  Waits for `stream`.  second_looks: wave-level groups (256
+ * coefficients of 16 units) in which at least one coefficient was not decided by the fp32 first look and
+ * all five digits were consulted; exact_units: units left undecided by both looks and recomputed with the
+ * reference's ordered fp64 chain (the arbiter).  On noise exact_units / units is ~1e-7; a regression of
+ * the accept thresholds to "accept everything" shows up as both counters stuck at zero on inputs built
+ * to sit on rounding boundaries (tests/test_screen_pinning.py). */
+typedef struct mi355_jpeg_screen_counts {
+    uint64_t second_looks;
+    uint64_t exact_units;
+} mi355_jpeg_screen_counts;
+int mi355_jpeg_screen_stats(mi355_jpeg_ctx *ctx, void *stream, mi355_jpeg_screen_counts *out, int reset);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ F_420 = 4       # with F_STANDARD: real 4:2:0 MCUs
 F_RESTART = 8   # with F_STANDARD: restart intervals of 64 MCUs (DRI/RSTm written by encode_jfif)
 F_DEFAULT = F_CDS
 
-OK, E_ARG, E_NO_DEVICE, E_CAPACITY, E_CATEGORY, E_ALLOC, E_TABLE, E_HIP = 0, -1, -2, -3, -4, -5, -6, -100
+OK, E_ARG, E_NO_DEVICE, E_CAPACITY, E_CATEGORY, E_ALLOC, E_TABLE, E_INTERNAL, E_HIP = 0, -1, -2, -3, -4, -5, -6, -7, -100
 
 
 class HuffTable(C.Structure):
@@ -34,6 +34,10 @@ class HuffTable(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("transform_ms", C.c_float), ("size_ms", C.c_float), ("scan_ms", C.c_float),
                 ("emit_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+class ScreenStats(C.Structure):
+    _fields_ = [("second_looks", C.c_uint64), ("exact_units", C.c_uint64)]
 
 
 class JpegError(RuntimeError):
@@ -52,7 +56,8 @@ ABI_SYMBOLS = [
     "mi355_jpeg_entropy_only", "mi355_jpeg_set_profiling", "mi355_jpeg_last_timings",
     "mi355_jpeg_profile_summary", "mi355_jpeg_synth_lcg_device", "mi355_jpeg_stuff_device", "mi355_jpeg_pool_create", "mi355_jpeg_pool_destroy", "mi355_jpeg_pool_workers",
     "mi355_jpeg_pool_set_quant", "mi355_jpeg_pool_set_quality", "mi355_jpeg_pool_encode",
-    "mi355_jpeg_set_encode_waves", "mi355_jpeg_wrap_jfif",
+    "mi355_jpeg_set_encode_waves", "mi355_jpeg_wrap_jfif", "mi355_jpeg_scan_bound_flags",
+    "mi355_jpeg_last_call_launches", "mi355_jpeg_screen_stats",
 ]
 
 _lib = None
@@ -97,6 +102,10 @@ def lib():
         L.mi355_jpeg_padded_size.restype = None
         L.mi355_jpeg_scan_bound.argtypes = [u32, u32]
         L.mi355_jpeg_scan_bound.restype = sz
+        L.mi355_jpeg_scan_bound_flags.argtypes = [u32, u32, u32]
+        L.mi355_jpeg_scan_bound_flags.restype = sz
+        L.mi355_jpeg_last_call_launches.argtypes = [vp, C.POINTER(u32)]
+        L.mi355_jpeg_screen_stats.argtypes = [vp, vp, C.POINTER(ScreenStats), C.c_int]
         L.mi355_jpeg_encode_scan.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, u64p]
         L.mi355_jpeg_encode_scan_device.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, vp, vp]
         L.mi355_jpeg_sync.argtypes = [vp, vp]
@@ -140,8 +149,8 @@ def reference_huffman(table):
     return np.array(t.code, np.uint32), np.array(t.len, np.uint8)
 
 
-def scan_bound(W, H):
-    return lib().mi355_jpeg_scan_bound(W, H)
+def scan_bound(W, H, flags=0):
+    return lib().mi355_jpeg_scan_bound_flags(W, H, flags)
 
 
 class Encoder:
@@ -204,7 +213,7 @@ class Encoder:
             rgb = rgb[None]
         n, H, W, _ = rgb.shape
         if cap is None:
-            cap = scan_bound(W, H)
+            cap = scan_bound(W, H, flags)
         out = np.zeros((n, cap), np.uint8)
         bits = (C.c_uint64 * n)()
         _check(lib().mi355_jpeg_encode_scan(self._h, rgb.ctypes.data, W, H, n, flags, out.ctypes.data,
@@ -214,7 +223,7 @@ class Encoder:
     def encode_jfif(self, rgb, flags=F_DEFAULT):
         rgb = np.ascontiguousarray(rgb, np.uint8)
         H, W, _ = rgb.shape
-        cap = 2 * scan_bound(W, H) + 4096
+        cap = 2 * scan_bound(W, H, flags) + 4096
         out = np.empty(cap, np.uint8)
         n = C.c_size_t()
         _check(lib().mi355_jpeg_encode_jfif(self._h, rgb.ctypes.data, W, H, flags, out.ctypes.data, cap,
@@ -296,6 +305,18 @@ class Encoder:
         t, n = Timings(), C.c_uint32()
         _check(lib().mi355_jpeg_profile_summary(self._h, C.byref(t), C.byref(n)))
         return {k: getattr(t, k) for k, _ in Timings._fields_}, n.value
+
+    def last_call_parts(self):
+        """Launches of the block-encode kernel the last encode call was split into."""
+        n = C.c_uint32()
+        _check(lib().mi355_jpeg_last_call_launches(self._h, C.byref(n)))
+        return n.value
+
+    def screen_stats(self, reset=False, stream=0):
+        """(second looks, units recomputed by the exact fp64 chain) since creation / the last reset."""
+        st = ScreenStats()
+        _check(lib().mi355_jpeg_screen_stats(self._h, stream, C.byref(st), int(reset)))
+        return st.second_looks, st.exact_units
 
     def last_timings(self):
         t = Timings()

@@ -43,6 +43,7 @@ struct ScreenParams {
     uint32_t region_words;  // private region of each persistent wave (bump-allocated without atomics)
     uint32_t overflow_base; // first word of the shared overflow pool (= grid * region_words)
     uint32_t* counters;     // [0] overflow-pool words used
+    unsigned long long* stats;  // [0] second looks (wave-level groups), [1] units recomputed by the exact chain
     uint32_t prio_from_wg;  // k_screen_encode: workgroups >= this raise their issue priority (0xFFFFFFFF: none)
     uint32_t* status;
     uint32_t* tile_bits;    // [frame][tile] bit totals, accumulated with atomics (zero on entry)

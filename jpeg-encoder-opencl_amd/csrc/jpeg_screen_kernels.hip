@@ -830,6 +830,7 @@ __global__ void __launch_bounds__(256, 2)
                 }
                 if (__any(a1[0] || a1[1] || a1[2] || a1[3])) {
                     // second look in fp64 with the least significant digit included (wave-uniform, rare)
+                    if (lane == 0) atomicAdd(&sp.stats[0], 1ull);
                     uint4 t0 = sp.afrag[(mt * kScreenLimbs) * 64 + lane];
                     v4i acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w}, B,
                                                                      v4i{0, 0, 0, 0}, 0, 0, 0);
@@ -903,6 +904,7 @@ __global__ void __launch_bounds__(256, 2)
             while (todo) {  // wave-uniform: one unit at a time, the whole wave on it
                 const uint32_t ul = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
+                if (lane == 0) atomicAdd(&sp.stats[1], 1ull);
                 const uint32_t ub = tile * 64 + ul, uby = ub / g.nbx, ubx = ub - uby * g.nbx;
                 exact_unit_wave(f, g, chan, ubx, uby, sp.qd, reinterpret_cast<double*>(s_slot), &s_tbuf[ul * 33], &s_mlo[ul],
                                 &s_mhi[ul], lane);
@@ -1056,7 +1058,12 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
     __shared__ uint32_t s_words[kWindow];
     const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
     const uint32_t tile = blockIdx.x, frame = blockIdx.y;
-    if (*status) return;
+    // one read per workgroup, behind a barrier: waves that saw different values of a status word another
+    // part's kernel is setting right now would otherwise diverge around the barriers below
+    __shared__ uint32_t s_status;
+    if (tid == 0) s_status = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_status) return;
     if (lds_words_limit > kWindow) lds_words_limit = kWindow;
     const size_t ft0 = (size_t)frame * g.tiles;
     const uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);

@@ -147,7 +147,9 @@ struct mi355_jpeg_ctx {
     double* d_qconst = nullptr;     // [2][64][4] accept thresholds for the current tables
     float* d_qconst_f = nullptr;    // [2][16][8] fp32 first-look scale factors and thresholds
     uint32_t* d_lut2 = nullptr;     // [2 modes][2][16][64] whole AC symbols for |value| <= 31
-    uint32_t* d_counters = nullptr; // [0] arena overflow-pool words ([1] unused)
+    uint32_t* d_counters = nullptr; // [0..7] arena overflow-pool words of the parts of a batch
+    unsigned long long* d_stats = nullptr;  // [0] second looks, [1] exact units (mi355_jpeg_screen_stats)
+    uint32_t last_launches = 0;     // block-encode launches of the last encode call
     uint2* d_meta = nullptr;
     size_t meta_cap = 0;
     uint32_t* d_arena = nullptr;
@@ -197,6 +199,11 @@ int ensure(T*& p, size_t& cap, size_t need, bool zero = false) {
 }
 
 int upload_tables(mi355_jpeg_ctx* c) {
+    // The copies below run on the null stream; encode calls run on the caller's (usually non-blocking)
+    // streams, which do not order themselves against it in either direction.  Wait for everything in
+    // flight first, or kernels of earlier calls could read a half-updated table set (quantiser
+    // divisors, accept thresholds and Huffman LUTs that do not belong together).
+    HIP_TRY(hipDeviceSynchronize());
     double q[128];
     for (int i = 0; i < 64; ++i) {
         q[i] = (double)c->qlum[i];
@@ -379,6 +386,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.arena = c->d_arena;
     sp.arena_words = (uint32_t)(arena_words > 0xFFFFFFFFull ? 0xFFFFFFFFull : arena_words);
     sp.counters = c->d_counters;
+    sp.stats = c->d_stats;
     sp.status = c->d_status;
     sp.tile_bits = c->d_tile_bits;
     sp.coefs = coefs;
@@ -522,6 +530,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         HIP_TRY(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
     }
     record(c, 0, s);
+    c->last_launches = nparts;
     for (uint32_t i = 0; i < nparts; ++i) {
         const ScreenParams sp = part_params(c, g, part[i]);
         HIP_TRY(launch_screen_encode(g, part[i].nf, d_rgb + (size_t)part[i].f0 * g.frame_stride, sp, false,
@@ -564,6 +573,7 @@ int run_screened_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, u
 }
 
 int status_to_error(uint32_t st) {
+    if (st & 4u) return MI355_E_INTERNAL;
     if (st & 1u) return MI355_E_CATEGORY;
     if (st & 2u) return MI355_E_CAPACITY;
     return MI355_OK;
@@ -583,7 +593,8 @@ const char* mi355_jpeg_strerror(int status) {
         case MI355_E_CAPACITY: return "output buffer too small";
         case MI355_E_CATEGORY: return "coefficient size category outside the Huffman tables";
         case MI355_E_ALLOC: return "allocation failed";
-        case MI355_E_TABLE: return "malformed table";
+        case MI355_E_TABLE: return "malformed table (or quantiser entries > 255 in a JFIF container)";
+        case MI355_E_INTERNAL: return "internal error: a device-side wait gave up";
         default: break;
     }
     if (status <= MI355_E_HIP) return hipGetErrorString((hipError_t)(MI355_E_HIP - status));
@@ -631,8 +642,10 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst_f, 256 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut2, 4096 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) != hipSuccess)
+        hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->d_stats, 2 * sizeof(unsigned long long)) != hipSuccess)
         e = MI355_E_ALLOC;
+    if (!e) e = hip_err(hipMemset(c->d_stats, 0, 2 * sizeof(unsigned long long)));
     if (!e) e = hip_err(hipMemset(c->d_status, 0, sizeof(uint32_t)));
     if (!e) e = hip_err(hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t)));
     if (!e) e = upload_afrag(c);
@@ -655,7 +668,7 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
                     c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
                     c->d_counters, c->d_meta,     c->d_arena,  c->d_lut2,     c->d_qconst_f,
-                    c->d_stuff_counts, c->d_stuff_offs, c->d_qzz};
+                    c->d_stuff_counts, c->d_stuff_offs, c->d_qzz, c->d_stats};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& es : c->ev_pool)
@@ -736,10 +749,17 @@ void mi355_jpeg_padded_size(uint32_t W, uint32_t H, uint32_t* W8, uint32_t* H8) 
     if (H8) *H8 = (H + 7) / 8 * 8;
 }
 
-size_t mi355_jpeg_scan_bound(uint32_t W, uint32_t H) {
+size_t mi355_jpeg_scan_bound(uint32_t W, uint32_t H) { return mi355_jpeg_scan_bound_flags(W, H, 0); }
+
+size_t mi355_jpeg_scan_bound_flags(uint32_t W, uint32_t H, uint32_t flags) {
     // per unit at most: DC 11+11 bits, 63 x (17+10) AC bits, EOB 4 -> 1727 bits
-    size_t units = (size_t)((W + 7) / 8) * ((H + 7) / 8) * 3;
-    return (units * 1727 + 7) / 8 + 8;
+    const bool s420 = (flags & MI355_F_420) != 0;
+    const uint32_t A = s420 ? 16 : 8;
+    const size_t mcus = (size_t)((W + A - 1) / A) * ((H + A - 1) / A);
+    const size_t units = mcus * (s420 ? 6 : 3);
+    size_t bits = units * 1727;
+    if (flags & MI355_F_RESTART) bits += ((mcus + 63) / 64) * 7;  // every interval (64 MCUs) padded to a byte
+    return (bits + 7) / 8 + 8;
 }
 
 int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t W, uint32_t H,
@@ -764,6 +784,7 @@ int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t
     }
     if ((e = ensure_workspace(c, g, n_frames))) return e;
     record(c, 0, s);
+    c->last_launches = 1;
     HIP_TRY(launch_transform(g, n_frames, (const uint8_t*)d_rgb, c->d_q, c->d_coefs, c->transform_mode, s));
     record(c, 1, s);
     return run_entropy(c, g, n_frames, (uint8_t*)d_out, out_stride, d_bits, s);
@@ -1008,6 +1029,13 @@ void dht_segment(Writer& w, int cls_id, const mi355_huff_table& t) {
     for (int i = 0; i < 16; ++i) w.b(bits[i]);
     for (uint8_t v : vals) w.b(v);
 }
+// the container writes 8-bit DQT segments: quantiser entries above 255 (set_quant takes up to 65535 for the
+// scan entry points) cannot be expressed and would silently decode with other tables
+bool dqt_fits(const mi355_jpeg_ctx* c) {
+    for (int i = 0; i < 64; ++i)
+        if (c->qlum[i] > 255 || c->qchrom[i] > 255) return false;
+    return true;
+}
 // header of the build-defined container: SOI, APP0, DQT x2, SOF0, DHT x4, SOS; returns its length
 size_t jfif_header(const mi355_jpeg_ctx* c, uint32_t W, uint32_t H, uint32_t flags, uint8_t* dst, size_t cap) {
     static const uint8_t zz[64] = MI355_ZIGZAG_TABLE;
@@ -1043,6 +1071,7 @@ int mi355_jpeg_wrap_jfif(mi355_jpeg_ctx* c, const uint8_t* scan, uint64_t n_bits
     if (!c || !scan || !out || !out_len || W == 0 || H == 0 || W > 65535u || H > 65535u) return MI355_E_ARG;
     if ((flags & MI355_F_420) && !(flags & MI355_F_STANDARD)) return MI355_E_ARG;
     if (flags & MI355_F_RESTART) return MI355_E_ARG;  // the markers go in with the stuffing, on the device
+    if (!dqt_fits(c)) return MI355_E_TABLE;
     Writer w{out, jfif_header(c, W, H, flags, out, cap), cap};
     const size_t nb = (size_t)((n_bits + 7) / 8);
     for (size_t i = 0; i < nb; ++i) {  // entropy bytes: last partial byte padded with 1s, 0xFF -> 0xFF 0x00
@@ -1062,6 +1091,7 @@ int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, ui
     Geom g;
     int e = make_geom(W, H, flags, nullptr, &g);
     if (e) return e;
+    if (!dqt_fits(c)) return MI355_E_TABLE;
     HIP_TRY(hipSetDevice(c->device));
     std::vector<uint8_t> hdr(1024);
     const size_t hlen = jfif_header(c, W, H, flags, hdr.data(), hdr.size());
@@ -1069,7 +1099,7 @@ int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, ui
 
     // scan on the device, stuffed on the device (k_stuff_*), one copy back
     size_t scan_cap = (size_t)W * H + 4096;  // 8 bits per pixel first; the worst-case bound on overflow
-    const size_t bound = mi355_jpeg_scan_bound(W, H);
+    const size_t bound = mi355_jpeg_scan_bound_flags(W, H, flags);
     if (scan_cap > bound) scan_cap = bound;
     if ((e = ensure(c->d_in, c->in_cap, (size_t)g.frame_stride))) return e;
     if ((e = ensure(c->d_bits, c->bits_cap, (size_t)2))) return e;
@@ -1347,6 +1377,27 @@ int mi355_jpeg_pool_encode(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W, u
 }
 
 // ---- measurement ---------------------------------------------------------------
+
+int mi355_jpeg_last_call_launches(mi355_jpeg_ctx* c, uint32_t* n) {
+    if (!c || !n) return MI355_E_ARG;
+    *n = c->last_launches;
+    return MI355_OK;
+}
+
+int mi355_jpeg_screen_stats(mi355_jpeg_ctx* c, void* stream, mi355_jpeg_screen_counts* out, int reset) {
+    if (!c || !out) return MI355_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    out->second_looks = h[0];
+    out->exact_units = h[1];
+    if (reset) {
+        HIP_TRY(hipMemset(c->d_stats, 0, sizeof h));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+    }
+    return MI355_OK;
+}
 
 int mi355_jpeg_set_profiling(mi355_jpeg_ctx* c, int mode) {
     if (!c || mode < 0 || mode > 2) return MI355_E_ARG;

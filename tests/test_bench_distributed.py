@@ -1,6 +1,10 @@
 """The N>1 path of bench.py (one process per GPU, frames sharded over ranks, barrier +
 max-over-ranks timing, no data-path collective) rehearsed on CPU: world_size 2, gloo, with
-the oracle as the worker on tiny frames (bench.py --dry-run-cpu, test-only)."""
+the oracle as the worker on tiny frames (bench.py --dry-run-cpu, test-only).
+
+Two ways in, same worker code: `python bench.py --gpus N` alone (bench.py starts its own N worker
+processes before anything touches a GPU -- the shape of the command the driver runs) and under
+torchrun (RANK/WORLD_SIZE already in the environment)."""
 import json
 import os
 import subprocess
@@ -9,22 +13,33 @@ import sys
 import oracle_lib as ol
 from conftest import ROOT
 
+BENCH = os.path.join(ROOT, "bench.py")
+ARGS = ["--steps", "3", "--warmup", "1", "--frames-per-step", "3", "--dry-run-cpu"]
 
-def run_bench(nproc, port):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(nproc), "--steps", "6", "--warmup", "2", "--ring", "3", "--dry-run-cpu"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
+
+def parse(out):
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     return json.loads(line)
 
 
-def test_two_ranks_shard_frames_without_overlap():
-    r = run_bench(2, 29731)
-    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["steps"] == 6
+def run_launcher_free(nproc):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    cmd = [sys.executable, BENCH, "--gpus", str(nproc)] + ARGS
+    return parse(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300))
+
+
+def run_torchrun(nproc, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", str(nproc)] + ARGS
+    return parse(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300))
+
+
+def check_two_ranks(r):
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["scaling"] == "weak" and r["steps"] == 3
     assert r["seed0_per_rank"] == [1, 4]          # rank 0: seeds 1..3, rank 1: seeds 4..6
+    assert len(r["per_rank_mpixel_s"]) == 2 and all(v > 0 for v in r["per_rank_mpixel_s"])
     # every rank really encoded its own frames: bit counts equal the oracle's for those seeds
     for rank, bits in enumerate(r["bits_per_rank"]):
         for k, b in enumerate(bits):
@@ -32,6 +47,28 @@ def test_two_ranks_shard_frames_without_overlap():
     assert r["value"] > 0
 
 
+def test_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2`: bench.py spawns its two workers itself."""
+    r = run_launcher_free(2)
+    assert r["launcher"] == "bench.py"
+    check_two_ranks(r)
+
+
+def test_two_ranks_under_torchrun():
+    r = run_torchrun(2, 29731)
+    assert r["launcher"] == "external"
+    check_two_ranks(r)
+
+
 def test_single_rank_same_code_path():
-    r = run_bench(1, 29732)
-    assert r["n_gpus"] == 1 and r["seed0_per_rank"] == [1]
+    r = run_launcher_free(1)
+    assert r["n_gpus"] == 1 and r["seed0_per_rank"] == [1] and r["ranks_seen"] == 1
+
+
+def test_a_dead_rank_fails_the_run():
+    """A worker that exits non-zero makes `bench.py --gpus N` exit non-zero (and not hang)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["MI355_BENCH_TEST_FAIL_RANK"] = "1"
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dead-rank-grace", "5"] + ARGS, env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3, (out.returncode, out.stderr[-500:])

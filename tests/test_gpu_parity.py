@@ -679,3 +679,67 @@ def test_device_lcg_generator_and_stuffing(jpeg, enc):
     n_out = int(d_bits[1])
     assert n_out == len(ref)
     assert d_out[:n_out].cpu().numpy().tobytes() == bytes(ref)
+
+
+def test_table_setter_between_pipelined_calls(jpeg):
+    """a table setter between two encode calls on a non-blocking stream, with no sync in
+    between, must not let the first call's kernels read a half-updated table set: both frames equal the
+    oracle under the tables each call was issued with."""
+    import torch
+    W, H, n = 1920, 1080, 6
+    dev = torch.device("cuda", 0)
+    frames = np.stack([ol.lcg_frame(W, H, 40 + f) for f in range(n)])
+    d_rgb = torch.from_numpy(frames).to(dev)
+    cap = 4 << 20
+    e2 = jpeg.Encoder(0)
+    st = torch.cuda.Stream(device=dev)
+    d_out = torch.zeros((2, n, cap), dtype=torch.uint8, device=dev)
+    d_bits = torch.zeros((2, n), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        e2.set_quality(50)
+        e2.encode_scan_device(d_rgb.data_ptr(), W, H, n, d_out[0].data_ptr(), cap, d_bits[0].data_ptr(), stream=st.cuda_stream)
+        e2.set_quality(90)   # no sync by the caller: the setter itself must wait for the call in flight
+        e2.encode_scan_device(d_rgb.data_ptr(), W, H, n, d_out[1].data_ptr(), cap, d_bits[1].data_ptr(), stream=st.cuda_stream)
+        e2.sync(st.cuda_stream)
+        for k, q in enumerate((50, 90)):
+            ql, qc = ol.quant_tables(q)
+            for f in (0, n - 1):
+                o = ol.oracle_encode(frames[f], ql, qc, True)
+                assert int(d_bits[k, f]) == o.n_bits, (rep, q, f)
+                assert np.array_equal(d_out[k, f, :(o.n_bits + 7) // 8].cpu().numpy(), o.bits), (rep, q, f)
+    e2.close()
+
+
+def test_jfif_refuses_quantisers_above_255(jpeg, enc):
+    """the container holds 8-bit DQT tables; entries > 255 are fine for the scan entry points
+    but a file would silently carry other tables than the ones used."""
+    rgb = ol.lcg_frame(64, 48, 3)
+    ql, qc = ol.quant_tables(50)
+    ql = ql.copy()
+    ql[5] = 300
+    enc.set_quant(ql, qc)
+    bits, nb = enc.encode_scan(rgb)            # the scan itself is defined (and equals the oracle)
+    o = ol.oracle_encode(rgb, ql, qc, True)
+    assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits)
+    with pytest.raises(jpeg.JpegError) as ei:
+        enc.encode_jfif(rgb)
+    assert ei.value.status == jpeg.E_TABLE
+    with pytest.raises(jpeg.JpegError) as ei:
+        enc.wrap_jfif(bits[0], nb[0], 64, 48)
+    assert ei.value.status == jpeg.E_TABLE
+    set_quality(enc, 50)
+
+
+def test_screen_counters_are_exposed(jpeg):
+    """mi355_jpeg_screen_stats: on noise the second look is taken now and then, the exact chain almost never;
+    with the accept margins widened (debug knob) every unit goes through the exact chain."""
+    e2 = jpeg.Encoder(0)
+    rgb = ol.lcg_frame(1920, 1080, 7)
+    e2.screen_stats(reset=True)
+    e2.encode_scan(rgb)
+    looks, exact = e2.screen_stats()
+    units = 3 * (1920 // 8) * (1080 // 8)
+    assert 0 < looks < units // 4          # groups of 16 units; a small share of them
+    assert exact < units // 1000
+    e2.close()

@@ -347,3 +347,26 @@ def test_gpu_standard_randomised_sweep(jpeg, enc):
             assert enc.encode_jfif(rgb, flags | jpeg.F_RESTART) == ol.oracle_std_jfif_restart(rgb, ql, qc, ss, 64), \
                 (it, W, H, q, ss, kind)
     enc.set_quality(50)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags_extra", [0, 8], ids=["plain", "restart"])
+def test_gpu_tiny_420_noise_at_q100_fits_the_flag_aware_bound(jpeg, enc, flags_extra):
+    """an 8x8 image in 4:2:0 is one MCU of SIX units (mi355_jpeg_scan_bound counted three); the
+    one-call file entry point must not run out of capacity on tiny noisy images at high quality."""
+    flags = jpeg.F_STANDARD | jpeg.F_420 | flags_extra
+    assert jpeg.scan_bound(8, 8, flags) >= 2 * jpeg.scan_bound(8, 8, 0) - 16
+    rng = np.random.default_rng(5)
+    ql, qc = ol.quant_tables(100)
+    enc.set_quant(ql, qc)
+    for W, H in [(8, 8), (9, 16), (24, 8)]:
+        for _ in range(4):
+            rgb = (rng.integers(0, 2, (H, W, 3)) * 255).astype(np.uint8)
+            got = enc.encode_jfif(rgb, flags)
+            if flags_extra:
+                assert got == ol.oracle_std_jfif_restart(rgb, ql, qc, subsample=1)
+            else:
+                o = ol.oracle_std_encode(rgb, ql, qc, subsample=1)
+                assert got == ol.jfif_frame(o.bits, o.n_bits, W, H, ql, qc, 1)
+            assert pil_decode(got).shape == rgb.shape
+    enc.set_quality(50)

@@ -133,8 +133,13 @@ def main():
             cases.append(case_record("%s_q%d" % (name, q), rgb, q, True)[0])
 
     if args.big:
+        # bench.py re-hashes the first frames of every rank's batch (rank r owns seeds 1 + 128 r ...) and the
+        # configs[2] test samples its 1024 frames: more pinned frames of those two shapes
+        extra = [(3840, 2160, s, 50, True) for s in (2, 3, 4)] + \
+                [(3840, 2160, 1 + 128 * r, 50, True) for r in range(1, 8)] + \
+                [(1920, 1080, s, 75, True) for s in (2, 513, 1024)]
         for (W, H, seed, q, cds) in [(3840, 2160, 1, 50, True), (1920, 1080, 1, 75, True),
-                                     (2048, 2048, 1, 90, False)]:
+                                     (2048, 2048, 1, 90, False)] + extra:
             rgb = ol.lcg_frame(W, H, seed)
             rec = case_record("lcg_%dx%d_s%d_q%d_%s" % (W, H, seed, q, "cds" if cds else "nocds"),
                               rgb, q, cds)[0]
