@@ -367,6 +367,8 @@ def worker(args):
     dt, per_rank = gather_times(dt, dist, distributed, coll_dev)
     _, n_gold_after = verify_outputs("after the timed region", ref_bits, ref_out)
     del ref_out
+    nb0 = int(ref_bits[0])
+    scan0 = d_out[0, :(nb0 + 7) // 8].cpu().numpy()  # frame 0 as the timed region wrote it (the legs below reuse d_out)
 
     line = None
     if rank == 0:
@@ -461,8 +463,7 @@ def worker(args):
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         base, r = cpu_baseline()
         # the CPU path's bits for seed 1 against what the GPU wrote in the timed region
-        nb = int(ref_bits[0])
-        assert r.n_bits == nb and np.array_equal(np.asarray(r.bits), d_out[0, :(nb + 7) // 8].cpu().numpy()), \
+        assert r.n_bits == nb0 and np.array_equal(np.asarray(r.bits), scan0), \
             "GPU scan of frame seed 1 differs from the CPU path run in this process"
         line["cpu_baseline"] = base
         try:  # extra, never the reported baseline: all host threads at once

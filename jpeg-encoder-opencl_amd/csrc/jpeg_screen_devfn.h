@@ -1,0 +1,547 @@
+// Device-side building blocks of the screened (integer-MFMA) pipeline, shared by its two kernel
+// files: jpeg_fused_kernels.hip (the single-launch pipeline: block encode + in-kernel scan and merge)
+// and jpeg_screen_kernels.hip (the four-launch pipeline, still used for 4:2:0 standard mode and as the
+// A/B reference).  See jpeg_screen_kernels.hip's header comment for why the screen is bit-exact.
+#pragma once
+#include "jpeg_devfn.h"
+#include "jpeg_screen_tables.h"  // kScreenLimbs, kScreenFracBits (the tables themselves are uploaded by the host)
+
+namespace mi355 {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+// the zig-zag rows are written as packed uint32 pairs and read back as int16: tell TBAA
+typedef int16_t __attribute__((may_alias)) i16a;
+
+#ifndef MI355_WALK_UNROLL2
+#define MI355_WALK_UNROLL2 1
+#endif
+
+constexpr uint32_t kSlotWordsFull = 54;  // worst case 63*(17+10)+4 = 1705 bits
+
+// Zig-zag rows of a wave's 64 units in LDS: int16, laid out [position 0..64][unit].  Unit u's
+// coefficient at a position sits at int16 index pos * 64 + row_unit_off(u): units 0..31 use the low
+// halves of 32 consecutive dwords, units 32..63 the high halves.  The entropy walk reads "my unit's
+// coefficient at MY next non-zero position" -- 64 data-dependent positions per wave instruction --
+// and with this layout the 32 lanes of each LDS lane group always hit 32 different banks (the
+// stride-33 unit-major rows of round 1 collided at random: 38 % of the LDS-active cycles were bank
+// conflicts).  Position 64 is a zero sentinel row (read by lanes that have run out of non-zeros).
+constexpr uint32_t kRowWords = 65 * 32;  // dwords per wave
+__device__ __forceinline__ uint32_t row_unit_off(uint32_t u) { return ((u & 31u) << 1) | (u >> 5); }
+
+// ----------------------------------------------------------------------------
+// integer-exact colour conversion (performCSC, utils.cpp:92-110)
+//
+// Y  = (uint8)(0.299 R + 0.587 G + 0.114 B) evaluated in fp64 differs from the
+// decimal value (299R+587G+114B)/1000 by < 1e-13, so its truncation equals the
+// integer quotient unless the decimal value is itself an integer (remainder 0),
+// where the fp64 sum may land just below it: that case (1 pixel in 1000) is
+// evaluated in fp64.  For Cb/Cr, (c0 R + c1 G + c2 B)/1e6 + 128, the integer
+// quotient is exact for all 2^24 inputs.  Both statements are checked
+// exhaustively (tests: exhaustive colour conversion on the GPU path).
+// ----------------------------------------------------------------------------
+// STD = standard mode (not a behaviour of the reference): round to nearest
+// instead of truncating, clamp to 255; pure integer arithmetic.
+// (a * m) >> 32 for a, m < 2^24 on the full-rate 24-bit multiplier (v_mul_hi_u32 is quarter rate,
+// and the compiler cannot see the operand ranges behind the dot product).
+__device__ __forceinline__ uint32_t mulhi24(uint32_t a, uint32_t m) {
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(m), "v"(a));
+    return r;
+}
+// s / 1000 for s <= 255500 and s / 31250 for s < 8.1e6 (both checked exhaustively,
+// tests/test_standard_mode.py::test_division_constants)
+__device__ __forceinline__ uint32_t div1000(uint32_t s) { return mulhi24(s, 8589935u) >> 1; }
+__device__ __forceinline__ uint32_t div31250(uint32_t s) { return mulhi24(s, 8796094u) >> 6; }
+
+template <bool STD>
+__device__ __forceinline__ uint32_t csc_int(int chan, uint32_t r, uint32_t g, uint32_t b) {
+    if (chan == 0) {
+        uint32_t s = 299u * r + 587u * g + 114u * b;  // <= 255000
+        if constexpr (STD) return div1000(s + 500u);
+        uint32_t y = div1000(s);
+        if (s == __umul24(y, 1000u)) y = csc1(r, g, b, 0.299, 0.587, 0.114, 0.0);
+        return y;
+    } else {
+        // numerators divided by 32 (exact: every constant and 128e6 are multiples of 32)
+        const uint32_t s = chan == 1 ? 4000000u + 15625u * b - 5273u * r - 10352u * g
+                                     : 4000000u + 15625u * r - 13084u * g - 2541u * b;
+        if constexpr (STD) {
+            const uint32_t v = div31250(s + 15625u);
+            return v > 255u ? 255u : v;
+        }
+        return div31250(s);
+    }
+}
+
+template <bool STD>
+__device__ __forceinline__ uint32_t csc_int_at(const uint8_t* __restrict__ f, uint32_t W, uint32_t x,
+                                               uint32_t y, int chan) {
+    const uint8_t* p = f + ((size_t)y * W + x) * 3;
+    return csc_int<STD>(chan, p[0], p[1], p[2]);
+}
+
+// padded pixel (px,py) of channel chan, generic path (see sample_generic)
+template <bool STD>
+__device__ __forceinline__ uint32_t sample_generic_int(const uint8_t* __restrict__ f, const Geom& g,
+                                                       int chan, bool avg, uint32_t px, uint32_t py) {
+    uint32_t mx = px < g.W ? px : 2 * g.W - 1 - px;
+    uint32_t my = py < g.H ? py : 2 * g.H - 1 - py;
+    if (avg) {
+        uint32_t qx = mx & ~1u, qy = my & ~1u;
+        if (qx + 1 < g.W && qy + 1 < g.H) {
+            uint32_t s = csc_int_at<STD>(f, g.W, qx, qy, chan) + csc_int_at<STD>(f, g.W, qx + 1, qy, chan) +
+                         csc_int_at<STD>(f, g.W, qx, qy + 1, chan) + csc_int_at<STD>(f, g.W, qx + 1, qy + 1, chan);
+            return s >> 2;
+        }
+    }
+    return csc_int_at<STD>(f, g.W, mx, my, chan);
+}
+
+// Raw RGB of rows 2*gq, 2*gq+1 of block (bx,by): 2 x 24 bytes as six 8-byte loads (fast
+// path: the block lies inside the image and rows are 8-byte aligned).
+__device__ __forceinline__ void load_raw_rowpair(const uint8_t* __restrict__ f, const Geom& g, uint32_t bx,
+                                                 uint32_t by, uint32_t gq, uint32_t (&w)[12]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint2* p =
+            reinterpret_cast<const uint2*>(f + ((size_t)(by * 8 + gq * 2 + r) * g.W + bx * 8) * 3);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            uint2 v = p[j];
+            w[r * 6 + 2 * j] = v.x;
+            w[r * 6 + 2 * j + 1] = v.y;
+        }
+    }
+}
+
+// The same conversion on a pixel fetched as rg = R | G << 16 (one v_perm_b32 on the raw dwords) and b:
+// the R and G terms are one v_dot2 (16-bit lanes), so four instructions form the weighted sum
+// instead of six.  The chroma numerators are divisible by 32 for every input (all six constants
+// and 128e6 are), so floor(x / 1e6) == floor((x / 32) / 31250) with constants that fit 16 bits:
+// 168736/32 = 5273, 331264/32 = 10352, 500000/32 = 15625, 418688/32 = 13084, 81312/32 = 2541.
+// Same results as csc_int for all 2^24 inputs (the exhaustive colour conversion tests run this one).
+template <bool STD>
+__device__ __forceinline__ uint32_t csc_packed(int chan, uint32_t rg, uint32_t b) {
+    typedef short v2s __attribute__((ext_vector_type(2)));
+    const v2s RG = __builtin_bit_cast(v2s, rg);
+    if (chan == 0) {
+        const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, v2s{299, 587}, (int)(114u * b), false);
+        if constexpr (STD) return div1000(s + 500u);  // s <= 255000
+        uint32_t y = div1000(s);
+        if (s == __umul24(y, 1000u)) y = csc1(rg & 0xffffu, rg >> 16, b, 0.299, 0.587, 0.114, 0.0);
+        return y;
+    } else {
+        const int kb = chan == 1 ? 15625 : -2541;
+        const v2s K = chan == 1 ? v2s{-5273, -10352} : v2s{15625, -13084};
+        const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, K, 4000000 + kb * (int)b, false);  // (128e6 + ...) / 32
+        if constexpr (STD) {  // s < 4000000 + 15625 * 255 < 8e6
+            const uint32_t v = div31250(s + 15625u);
+            return v > 255u ? 255u : v;
+        }
+        return div31250(s);
+    }
+}
+
+// 16 samples of channel CHAN from the raw row pair, packed 4 per dword in sample order
+// (y*8+x), as unsigned bytes; chroma averaging over the 2x2 quads of the row pair.
+template <int CHAN, bool STD>
+__device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool avg, uint32_t (&pk)[4]) {
+    uint32_t val[2][8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            // pixel x = bytes 3x, 3x+1, 3x+2 of the row: R and G through a byte permute of the two
+            // dwords around them (selector 0..3 = low dword, 4..7 = high dword, 0x0c = zero)
+            constexpr uint32_t kZ = 0x0cu;
+            const int o = 3 * x, i = o >> 2, k = o & 3;
+            const uint32_t lo = w[r * 6 + i], hi = w[r * 6 + (i < 5 ? i + 1 : i)];
+            const uint32_t rg = __builtin_amdgcn_perm(hi, lo, (uint32_t)k | (kZ << 8) | ((uint32_t)(k + 1) << 16) | (kZ << 24));
+            const uint32_t b = (w[r * 6 + ((o + 2) >> 2)] >> (8 * ((o + 2) & 3))) & 255u;
+            val[r][x] = csc_packed<STD>(CHAN, rg, b);
+        }
+    if (avg) {
+#pragma unroll
+        for (int x = 0; x < 8; x += 2) {
+            uint32_t m = (val[0][x] + val[0][x + 1] + val[1][x] + val[1][x + 1]) >> 2;
+            val[0][x] = val[0][x + 1] = val[1][x] = val[1][x + 1] = m;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            pk[r * 2 + h] = val[r][4 * h] | (val[r][4 * h + 1] << 8) | (val[r][4 * h + 2] << 16) |
+                            (val[r][4 * h + 3] << 24);
+}
+
+// Edge / unaligned tiles: one sample at a time with mirroring.
+template <int CHAN, bool STD>
+__device__ __forceinline__ void generic_rowpair(const uint8_t* __restrict__ f, const Geom& g, bool avg,
+                                                uint32_t bx, uint32_t by, uint32_t gq, uint32_t (&pk)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t v = 0;
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            int s = i * 4 + j;  // 0..15 within the row pair
+            uint32_t smp = sample_generic_int<STD>(f, g, CHAN, avg, bx * 8 + (s & 7), by * 8 + gq * 2 + (s >> 3));
+            v |= smp << (8 * j);
+        }
+        pk[i] = v;
+    }
+}
+
+// ---- 4:2:0 standard mode: one chroma sample = rounded mean of the 2x2 converted samples ----
+// Raw RGB of pixel rows row0, row0+1 of MCU (mx,my): 2 x 48 bytes as twelve 8-byte loads (fast
+// path: every MCU of the wave interior, W % 8 == 0, base 8-aligned).
+__device__ __forceinline__ void load_raw_mcu_rows(const uint8_t* __restrict__ f, const Geom& g, uint32_t mx,
+                                                  uint32_t my, uint32_t row0, uint32_t (&w)[24]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint2* p = reinterpret_cast<const uint2*>(f + ((size_t)(my * 16 + row0 + r) * g.W + mx * 16) * 3);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            uint2 v = p[i];
+            w[r * 12 + 2 * i] = v.x;
+            w[r * 12 + 2 * i + 1] = v.y;
+        }
+    }
+}
+// One row of 8 chroma samples of channel CHAN from two pixel rows of 16, packed 4 per dword.
+template <int CHAN>
+__device__ __forceinline__ void convert_chroma420_row(const uint32_t (&w)[24], uint32_t (&pk2)[2]) {
+    uint32_t m[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        uint32_t sum = 2u;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                constexpr uint32_t kZ = 0x0cu;
+                const int o = 3 * (2 * x + h), i = o >> 2, k = o & 3;
+                const uint32_t lo = w[r * 12 + i], hi = w[r * 12 + (i < 11 ? i + 1 : i)];
+                const uint32_t rg = __builtin_amdgcn_perm(hi, lo, (uint32_t)k | (kZ << 8) | ((uint32_t)(k + 1) << 16) | (kZ << 24));
+                const uint32_t b = (w[r * 12 + ((o + 2) >> 2)] >> (8 * ((o + 2) & 3))) & 255u;
+                sum += csc_packed<true>(CHAN, rg, b);
+            }
+        m[x] = sum >> 2;
+    }
+    pk2[0] = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
+    pk2[1] = m[4] | (m[5] << 8) | (m[6] << 16) | (m[7] << 24);
+}
+// Edge MCUs: one chroma sample at a time, every contributing pixel mirrored on its own
+// (the checker pads the converted image, then averages).
+__device__ __forceinline__ void generic_chroma420(const uint8_t* __restrict__ f, const Geom& g, int chan,
+                                                  uint32_t mx, uint32_t my, uint32_t gq, uint32_t (&pk)[4]) {
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        uint32_t v = 0;
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int sidx = i * 4 + j;  // 0..15 within the chroma row pair 2gq, 2gq+1
+            const uint32_t px = mx * 16 + 2 * (sidx & 7), py = my * 16 + 2 * (gq * 2 + (sidx >> 3));
+            const uint32_t sum = sample_generic_int<true>(f, g, chan, false, px, py) +
+                                 sample_generic_int<true>(f, g, chan, false, px + 1, py) +
+                                 sample_generic_int<true>(f, g, chan, false, px, py + 1) +
+                                 sample_generic_int<true>(f, g, chan, false, px + 1, py + 1) + 2u;
+            v |= (sum >> 2) << (8 * j);
+        }
+        pk[i] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// device-side parameter block
+// ----------------------------------------------------------------------------
+// (ScreenParams is declared in jpeg_device.h)
+
+__device__ __forceinline__ int meta_dc(uint32_t y) { return (int)(int16_t)(y & 0xffffu); }
+
+// Arena allocation for one wave.  Every persistent wave owns a private region and bumps a
+// private pointer (no atomics: a returning atomic on one address saturates at ~88 per
+// microsecond chip-wide, far below the wave-tile rate).  A wave whose region is full takes
+// chunks from the shared overflow pool with one atomic per chunk.
+constexpr uint32_t kOverflowChunk = 1024;  // words
+struct WaveArena {
+    uint32_t ptr, left;
+    // returns the base word of `need` words, or 0xFFFFFFFF if the arena is exhausted
+    __device__ __forceinline__ uint32_t take(const ScreenParams& sp, uint32_t need, uint32_t lane) {
+        if (need > left) {
+            uint32_t grab = need > kOverflowChunk ? need : kOverflowChunk;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(sp.counters, grab);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if ((uint64_t)sp.overflow_base + base + grab > sp.arena_words) return 0xFFFFFFFFu;
+            ptr = sp.overflow_base + base;
+            left = grab;
+        }
+        uint32_t r = ptr;
+        ptr += need;
+        left -= need;
+        return r;
+    }
+};
+
+// ----------------------------------------------------------------------------
+// Unit walk as a loop over NON-ZERO coefficients (the work is proportional to what
+// actually gets coded).  The zig-zag row of the unit lives in LDS; a 64-bit
+// non-zero mask built during quantisation gives the positions (lowest set bit =
+// next coefficient, run = gap to the previous one).  A combined (run, value) LUT
+// returns the complete symbol -- Huffman code and value bits, left-aligned, length
+// in the low five bits -- for |value| <= 31; larger values assemble it from the
+// (run,size) table.  Bits are packed with 32-bit funnel shifts.  LDS reads are
+// software-pipelined two symbols ahead.  Same bits as walk_ac().
+// ----------------------------------------------------------------------------
+// The kernel's LDS is kept at 72,832 B per workgroup (24 slot rows, no fp64 threshold table), so that
+// next to the two resident workgroups of a CU one workgroup of k_merge (17,280 B) or k_dc_heads still
+// fits: another stream's tail kernels then run under this kernel instead of waiting for it.
+#ifndef MI355_SLOT_ROWS
+#define MI355_SLOT_ROWS 24
+#endif
+constexpr uint32_t kSlotRows = MI355_SLOT_ROWS;  // words per unit in the LDS slot; larger strings re-walk into global memory
+// Symbol table layout [run][value + 32]: the value-0 column (index 32) is all zero (no-op for
+// exhausted lanes, whatever their run); the unused value -32 column carries ZRL and EOB.
+constexpr uint32_t kLut2Zrl = 15 * 64 + 0;
+constexpr uint32_t kLut2Eob = 0;
+
+// Left-aligned 32-bit bit packer.  e = symbol bits left-aligned | length (<= 27) in bits 4..0.
+// Every put stores the word being filled (a later put to the same word overwrites it).
+template <typename Store>
+struct Packer32 {
+    uint32_t acc = 0;  // pending bits, left-aligned
+    uint32_t n = 0;    // pending count, 0..31
+    uint32_t w = 0;    // completed words
+    Store st;
+    __device__ __forceinline__ explicit Packer32(Store s) : st(s) {}
+    __device__ __forceinline__ void put(uint32_t e) {
+        const uint32_t ml = e & ~31u, t = e & 31u;
+        const uint32_t hi = acc | (ml >> n);
+        const uint32_t lo = __builtin_amdgcn_alignbit(ml, 0u, n);  // ml << (32-n), and 0 when n == 0
+        const uint32_t n2 = n + t;
+        st(w, hi);
+        const bool adv = n2 >= 32u;
+        acc = adv ? lo : hi;
+        w += n2 >> 5;
+        n = n2 & 31u;
+    }
+    __device__ __forceinline__ void finish() { st(w, acc); }
+    __device__ __forceinline__ uint32_t bits() const { return w * 32u + n; }
+    __device__ __forceinline__ uint32_t words() const { return w + (n ? 1u : 0u); }
+};
+
+struct StoreLds {  // [word][lane]: `rows` words per unit; later words of an oversized string land in a dump word
+    uint32_t* slot;  // this lane's column
+    uint32_t rows;   // words per unit that are kept
+    uint32_t dump;   // word offset (from slot) of this lane's dump word
+    __device__ __forceinline__ void operator()(uint32_t w, uint32_t v) const { slot[w < rows ? w * 64u : dump] = v; }
+};
+struct StoreGlobal {  // lane-private run of kSlotWordsFull words
+    uint32_t* dst;
+    __device__ __forceinline__ void operator()(uint32_t w, uint32_t v) const {
+        dst[w < kSlotWordsFull - 1 ? w : kSlotWordsFull - 1] = v;
+    }
+};
+
+// Symbol for (run r < 16, value v != 0): LUT2 hit for |v| <= 31, else from the (run,size) table.
+// Returns 0 when the reference has no code for it (quirk Q13).
+__device__ __forceinline__ uint32_t symbol_slow(int v, uint32_t r, const uint32_t* __restrict__ act) {
+    const int size = bit_size(v);
+    if (size > 10) return 0u;
+    const uint32_t a = act[(r << 4) | (uint32_t)size];
+    const uint32_t len = lut_len(a);
+    if (len == 0u) return 0u;
+    const uint32_t t = len + (uint32_t)size;  // <= 27
+    const uint32_t m = (lut_code(a) << size) | value_bits(v, size);
+    return (m << (32u - t)) | t;
+}
+
+// Wave-wide inclusive prefix sum / maximum with DPP row shifts and row broadcasts (6 VALU
+// instructions, no LDS round trips like __shfl).  Lane 63 ends up with the reduction.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_src(uint32_t v) {
+    // lanes without a valid source (or outside ROW_MASK) read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/) {
+    v += dpp_src<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_src<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_src<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_src<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_src<0x142, 0xa>(v);  // row_bcast:15 into rows 1, 3
+    v += dpp_src<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {  // uniform result
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63);
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {  // uniform result
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, dpp_src<0x111, 0xf>(v));
+    v = mx(v, dpp_src<0x112, 0xf>(v));
+    v = mx(v, dpp_src<0x114, 0xf>(v));
+    v = mx(v, dpp_src<0x118, 0xf>(v));
+    v = mx(v, dpp_src<0x142, 0xa>(v));
+    v = mx(v, dpp_src<0x143, 0xc>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+struct WalkA {  // stage A result: position of a symbol + its value read in flight
+    uint32_t pos;
+    int v;
+};
+struct WalkB {  // stage B result: symbol entry read in flight
+    uint32_t e_fast;
+    uint32_t r;
+    uint32_t zc;
+    int v;
+    bool fast;
+};
+
+// row: this lane's unit in the [position][unit] row buffer (row[pos * 64] = coefficient at zig-zag
+// position pos; position 64 = 0, the sentinel); mask: non-zero
+// positions 1..63.  A lane that has run out of non-zeros keeps reading the sentinel: value 0
+// selects the all-zero column of the symbol table, i.e. a no-op put -- no validity bookkeeping.
+// maxcnt: wave-uniform upper bound of the lanes' non-zero counts (wave_max of popcount(mask),
+// formed by the caller with all lanes active: DPP reductions need the full wave).
+template <bool STD, typename Store>
+__device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, const uint32_t* __restrict__ lut2,
+                                              const uint32_t* __restrict__ act, Packer32<Store>& pk,
+                                              const uint32_t maxcnt) {
+    uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+    uint32_t prev = 0, coded = 0;
+
+    auto stageA = [&]() -> WalkA {
+        WalkA a;
+        const uint32_t plo = (uint32_t)(__ffs((int)mlo) - 1);  // 0xFFFFFFFF when mlo == 0
+        uint32_t phi = (uint32_t)(__ffs((int)mhi) - 1);        // 0xFFFFFFFF when mhi == 0
+        phi = (phi < 32u ? phi : 32u) + 32u;                   // ... -> 64 = the sentinel slot
+        a.pos = plo < phi ? plo : phi;
+        // clear the lowest set bit of the 64-bit mask
+        const uint32_t nlo = mlo & (mlo - 1u);
+        const uint32_t nhi = mlo ? mhi : (mhi & (mhi - 1u));
+        mlo = nlo;
+        mhi = nhi;
+        a.v = (int)row[a.pos * 64u];
+        return a;
+    };
+    auto stageB = [&](const WalkA& a) -> WalkB {
+        WalkB b;
+        const uint32_t run = a.pos - prev - 1u;
+        prev = a.pos;
+        b.v = a.v;
+        b.r = run & 15u;
+        b.zc = a.v != 0 ? (run >> 4) : 0u;
+        b.fast = (uint32_t)(b.v + 31) <= 62u;
+        const uint32_t idx = b.fast ? (b.r * 64u + (uint32_t)(b.v + 32)) : 32u;
+        b.e_fast = lut2[idx];
+        return b;
+    };
+    auto stageC = [&](const WalkB& b) {
+        uint32_t e = b.e_fast;
+        if (!b.fast) e = symbol_slow(b.v, b.r, act);
+        coded += e != 0u ? 1u : 0u;  // every non-zero coefficient must find a code (checked after the loop)
+        if (b.zc) {  // (15,0) at every 16th zero before a later non-zero
+            const uint32_t z = lut2[kLut2Zrl];
+            for (uint32_t i = 0; i < b.zc; ++i) pk.put(z);
+        }
+        pk.put(e);
+    };
+
+    WalkA a1 = stageA();
+    WalkA a2 = stageA();
+    WalkB b1 = stageB(a1);
+#if MI355_WALK_UNROLL2
+    // two symbols per trip: the pipeline registers rotate by renaming instead of by moves (an odd
+    // count runs one extra step on the sentinel, a no-op for every lane)
+    for (uint32_t i = 0; i < maxcnt; i += 2) {
+        WalkA a3 = stageA();
+        WalkB b2 = stageB(a2);
+        stageC(b1);
+        WalkA a4 = stageA();
+        WalkB b3 = stageB(a3);
+        stageC(b2);
+        a2 = a4;
+        b1 = b3;
+    }
+#else
+    for (uint32_t i = 0; i < maxcnt; ++i) {
+        WalkA a3 = stageA();
+        WalkB b2 = stageB(a2);
+        stageC(b1);
+        a2 = a3;
+        b1 = b2;
+    }
+#endif
+    // the reference appends EOB ALWAYS (quirk Q8); a standard encoder omits it after coefficient 63
+    if (!(STD && (mask >> 63))) pk.put(lut2[kLut2Eob]);
+    pk.finish();
+    return coded == (uint32_t)__popcll(mask);  // false: a size category without a code (quirk Q13)
+}
+
+// ----------------------------------------------------------------------------
+// k_screen_encode: 256-thread workgroups = 4 independent persistent waves that share
+// the constant tables in LDS.  One (tile, channel) per wave iteration.  Lane roles:
+// MFMA phase lane = (n = lane&15: block within a group of 16, gq = lane>>4: row pair
+// of the block / row group of the accumulator); walk phase lane = block.
+// ----------------------------------------------------------------------------
+// ----------------------------------------------------------------------------
+// The arbiter: the reference's ordered in-place fp64 chain (utils.cpp:314-348) for ONE unit, run by
+// the whole wave for a unit whose screened transform left a coefficient undecided (rare: ~1e-7 of
+// the units).  Lane l owns sample / coefficient l = y*8 + x.  Each of the 64 dependent steps (u
+// outer, v inner) forms its 64 terms (P[y][x]*C[x][u])*C[y][v] in parallel -- multiplying by
+// C[.][0] == 1.0 is the identity, so always multiplying changes nothing -- and lane 0 adds them in
+// the reference's order (y outer, x inner, from 0.0), scales, and publishes P[v][u].  About 25 us
+// per unit, but only a handful of registers and 520 bytes of LDS: no second kernel, no scratch.
+// Rewrites the unit's zig-zag row and non-zero mask in LDS; the caller then carries on as if the
+// screen had produced them.  All lanes must be active.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ void exact_unit_wave(const uint8_t* __restrict__ f, const Geom& g, uint32_t chan, uint32_t bx,
+                                                uint32_t by, const double* __restrict__ qd, double* lds /* 65 doubles */,
+                                                i16a* row /* the unit's column of the row buffer */, uint32_t* mlo,
+                                                uint32_t* mhi, uint32_t lane) {
+    static constexpr double kCos[8][8] = MI355_COS_TABLE;
+    static constexpr uint8_t kZz[64] = MI355_ZIGZAG_TABLE;  // zig-zag position -> natural index
+    const uint32_t y = lane >> 3, x = lane & 7;
+    const bool avg = (chan != 0) && (g.flags & 1u);
+    const uint32_t smp = sample_generic(f, g, avg, bx * 8 + x, by * 8 + y, csc_k(chan, 0), csc_k(chan, 1), csc_k(chan, 2),
+                                        csc_k(chan, 3));
+    double p = (double)((int)smp - 128);  // quirk Q4
+#pragma unroll 1
+    for (uint32_t u = 0; u < 8; ++u) {
+        const double cxu = kCos[x][u];
+#pragma unroll 1
+        for (uint32_t v = 0; v < 8; ++v) {
+            lds[lane] = (p * cxu) * kCos[y][v];
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                double sum = 0.0;
+#pragma unroll 8
+                for (int i = 0; i < 64; ++i) sum += lds[i];
+                sum *= (u == 0 && v == 0) ? kScale00 : ((u == 0 || v == 0) ? kScale0X : kScaleXX);
+                lds[64] = sum;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == v * 8 + u) p = lds[64];  // P[v][u] = s, before the next step (quirk Q5)
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    const int q = (int)__builtin_round(p / qd[(chan ? 64 : 0) + lane]);  // natural index v*8+u == lane (quirk Q6)
+    // natural order -> zig-zag order through LDS, then the non-zero mask by ballot
+    int* qn = reinterpret_cast<int*>(lds);
+    __builtin_amdgcn_wave_barrier();
+    qn[lane] = q;
+    __builtin_amdgcn_wave_barrier();
+    const int qz = qn[kZz[lane]];  // coefficient at zig-zag position `lane`
+    const uint64_t nz = __ballot(qz != 0);
+    row[lane * 64u] = (int16_t)qz;
+    if (lane == 0) {
+        *mlo = (uint32_t)nz & ~1u;  // bit 0 = "undecided" flag: cleared; coefficient 0 is not walked
+        *mhi = (uint32_t)(nz >> 32);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace mi355
