@@ -52,6 +52,23 @@ struct ScreenParams {
     unsigned long long* stamps;  // diagnostic build only (-DMI355_STAMPS): [wave][8] phase cycle sums
 };
 
+// Single-launch pipeline (jpeg_fused_kernels.hip): everything k_encode_fused needs besides the tables of `sp`.
+struct FusedParams {
+    ScreenParams sp;               // tables, status, stats, probe outputs (meta / arena / counters / tile_bits unused)
+    unsigned long long* rec;       // [frames * tiles][4] hand-off granules: {last DCs, scan state, carry word, -}
+    uint32_t* ticket;              // [0] next tile to hand out, [1] waves that have left (both 0 between launches)
+    uint32_t epoch;                // 1..65535, changes with every launch (tag of this launch's granules)
+    uint32_t* ovf;                 // [grid waves][3][54][64] overflow area for strings longer than their LDS slot
+    uint8_t* out;                  // frame f at out + f * out_stride (nullptr: stage probes, nothing is written)
+    uint64_t out_stride;
+    uint64_t* frame_bits;          // [frames]
+    uint64_t* tile_off;            // [frames][tiles + 1] bit offsets of the tiles (restart-interval stuffing reads them)
+};
+uint32_t fused_grid(const Geom& g, uint32_t n_frames, uint32_t max_wgs);
+size_t fused_ovf_words(uint32_t wgs);
+hipError_t launch_encode_fused(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const FusedParams& fp, bool probe,
+                               uint32_t wgs, hipStream_t s);
+
 // number of persistent single-wave workgroups launch_screen_encode will use
 uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves);
 hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,

@@ -488,6 +488,103 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
 // of the block / row group of the accumulator); walk phase lane = block.
 // ----------------------------------------------------------------------------
 // ----------------------------------------------------------------------------
+// Quantise + verify one 16x16x64 group of the map (positions 16 mt + 4 gq + r, r = 0..3, of unit
+// 16 j + n; B = the 16 units' level-shifted samples).
+//
+// First look: the top THREE of the five base-256 digits of Lt (A fragments resident in 12 VGPRs per row
+// tile).  Y' = acc4 * 2^16 + acc3 * 2^8 + acc2 is Lt p / 2^16 without the two low digits, so
+//     c/Q = Y' * 2^-23 / Q + e,   |e| <= (E1_R + delta_R) / Q,
+// E1_R = 128 * (256 * sum_i |digit1[R][i]| + sum_i |digit0[R][i]|) * 2^-39 (exact worst case of the dropped
+// digits, <= 2^-11; computed per row on the host), delta_R = eps_R + 2^-27 (chain rounding + map error).
+// In fp32: t = acc3 * 256 + acc2 (|t| < 2^28.1, its conversion is off by <= 2^4.1), acc4 converts exactly,
+// fv = fma(acc4, 2^16, fl(t)), zf = fl(fv * fl(2^-23/Q)): three roundings, |zf - Y' 2^-23/Q| <= |z| 2^-22 +
+// 2^-18/Q.  rn = nearest integer of zf by the 1.5 * 2^23 trick, d = zf - rn exact.  The quantised value is
+// rn whenever |d| + |zf| 2^-21 < 0.5 - (E1_R + 2^-18 + delta_R)/Q - 2^-22  (threshold rounded down on the host).
+// Second look (wave-uniform, a few per cent of the groups): the two low digits are fetched and all five
+// give y2 = Lt p exactly in fp64; threshold 0.5 - delta_R/Q (1 + 1e-6) - 2^-38.  Standard mode is DEFINED by
+// its integer map and decides exactly there.  What is still undecided sets `amb`: the exact ordered fp64
+// chain then recomputes the unit (exact_unit_wave) -- that chain remains the arbiter.
+// Position 0 (mt == 0, gq == 0, r == 0) is never judged here: coefficient 0 is formed exactly elsewhere.
+// ----------------------------------------------------------------------------
+constexpr int kLookDigits = 3;  // digits 2, 3, 4
+
+__device__ __forceinline__ void load_look_fragments(const ScreenParams& sp, uint32_t lane, v4i (&A)[4][kLookDigits]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int l = 0; l < kLookDigits; ++l) {
+            const uint4 t = sp.afrag[(mt * kScreenLimbs + (kScreenLimbs - kLookDigits) + l) * 64 + lane];
+            A[mt][l] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+        }
+}
+
+template <bool STD>
+__device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], const v4i& B, const ScreenParams& sp,
+                                                const float* __restrict__ qf /* LDS: sf[4], thr[4] of these positions */,
+                                                uint32_t ct, int mt, uint32_t gq, uint32_t lane, uint32_t (&qb)[4], bool& amb) {
+    v4i acc[kLookDigits];
+#pragma unroll
+    for (int l = 0; l < kLookDigits; ++l) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[l], B, v4i{0, 0, 0, 0}, 0, 0, 0);
+    int t[4];
+    v2f fA, fB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        t[r] = acc[1][r] * 256 + acc[0][r];
+        const float fv = __builtin_fmaf((float)acc[2][r], 65536.0f, (float)t[r]);
+        if (r < 2) fA[r] = fv;
+        else fB[r - 2] = fv;
+    }
+    const v2f sA = {qf[0], qf[1]}, sB = {qf[2], qf[3]};
+    const v2f M2 = {12582912.0f, 12582912.0f};
+    const v2f zA = fA * sA, zB = fB * sB;
+    const v2f aA = zA + M2, aB = zB + M2;
+    const v2f rA = aA - M2, rB = aB - M2;
+    const v2f dA = zA - rA, dB = zB - rB;
+    const float zz[4] = {zA[0], zA[1], zB[0], zB[1]};
+    const float aa[4] = {aA[0], aA[1], aB[0], aB[1]};
+    const float dd[4] = {dA[0], dA[1], dB[0], dB[1]};
+    bool a1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        qb[r] = __float_as_uint(aa[r]);  // 0x4B400000 + q
+        a1[r] = !(__builtin_fmaf(__builtin_fabsf(zz[r]), 0x1p-21f, __builtin_fabsf(dd[r])) < qf[4 + r]);
+        if (mt == 0 && r == 0 && gq == 0) a1[r] = false;  // coefficient 0: overwritten by the caller
+    }
+    if (__any(a1[0] || a1[1] || a1[2] || a1[3])) {
+        if (lane == 0) atomicAdd(&sp.stats[0], 1ull);
+        const uint4 t1 = sp.afrag[(mt * kScreenLimbs + 1) * 64 + lane], t0 = sp.afrag[(mt * kScreenLimbs) * 64 + lane];
+        const v4i acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w}, B,
+                                                               v4i{0, 0, 0, 0}, 0, 0, 0);
+        const v4i acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w}, B,
+                                                               v4i{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (a1[r]) {
+                // {s1, thr1, s2, thr2} of this position: read from memory, the second look is rare
+                const double* qc = sp.qconst + ((size_t)ct * 64 + 16 * mt + 4 * gq + r) * 4;
+                const double y1 = (double)acc[2][r] * 65536.0 + (double)t[r];                 // exact (< 2^37)
+                const double y2 = y1 * 65536.0 + (double)(acc1[r] * 256 + acc0[r]);          // exact (< 2^53)
+                if constexpr (STD) {
+                    // standard mode is DEFINED by the fixed-point map: decide exactly in integers
+                    const long long Y = (long long)y2;
+                    const unsigned long long Dq = (unsigned long long)sp.qnat_zz[ct * 64 + 16 * mt + 4 * gq + r] << 39;
+                    const unsigned long long a = (unsigned long long)(Y < 0 ? -Y : Y);
+                    const unsigned long long nn = (2 * a + Dq) / (2 * Dq);
+                    qb[r] = (uint32_t)(Y < 0 ? -(long long)nn : (long long)nn);
+                } else {
+                    const double z = y2 * qc[2];
+                    const double tt = __builtin_fabs(z) + 0.5;
+                    const double fr = tt - __builtin_floor(tt);
+                    const int nn = (int)tt;
+                    qb[r] = (uint32_t)(z < 0.0 ? -nn : nn);
+                    amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
 // The arbiter: the reference's ordered in-place fp64 chain (utils.cpp:314-348) for ONE unit, run by
 // the whole wave for a unit whose screened transform left a coefficient undecided (rare: ~1e-7 of
 // the units).  Lane l owns sample / coefficient l = y*8 + x.  Each of the 64 dependent steps (u

@@ -75,16 +75,10 @@ __global__ void __launch_bounds__(256, 2)
     if (tid < 32) s_dc[tid >> 4][tid & 15] = sp.lut[(tid >> 4) * 256 + (tid & 15)];
     if (lane < 32) s_tbuf[64 * 32 + lane] = 0;  // sentinel row after zig-zag position 63 (never written again)
     i16a* const tb16 = reinterpret_cast<i16a*>(s_tbuf);
-    // A fragments of digits 1..4 stay in registers; digit 0 only matters for the (rare)
-    // second look and is fetched on demand.
-    v4i A[4][kScreenLimbs - 1];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int l = 1; l < kScreenLimbs; ++l) {
-            uint4 t = sp.afrag[(mt * kScreenLimbs + l) * 64 + lane];
-            A[mt][l - 1] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
-        }
+    // A fragments of the top three digits stay in registers; the two low digits only matter for the
+    // (rare) second look and are fetched on demand.
+    v4i A[4][kLookDigits];
+    load_look_fragments(sp, lane, A);
     __syncthreads();
 
     // Work distribution.  With a grid that is a multiple of 8 workgroups, the waves of XCD x
@@ -266,75 +260,8 @@ __global__ void __launch_bounds__(256, 2)
             uint32_t nzlo = 0, nzhi = 0;  // this lane's part of the unit's non-zero mask
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                v4i acc[kScreenLimbs - 1];
-#pragma unroll
-                for (int l = 0; l < kScreenLimbs - 1; ++l)
-                    acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mt][l], B, v4i{0, 0, 0, 0}, 0, 0, 0);
-                // ---- first look in packed fp32.  V = floor(Y1 / 2^11), Y1 = hi*2^16 + mid (digits
-                // 4..1, exact integers), so c/Q = V*2^-20/Q + e with |e| < (2^-18 + delta)/Q (dropped
-                // low bits and digit 0, map error).  zf = fl(fl(V) * fl(2^-20/Q)) is within |z|*2^-22 of
-                // V*2^-20/Q.  rn = nearest integer of zf by the 1.5*2^23 trick, d = zf - rn exact.
-                // The quantised value is rn whenever |d| + |zf|*2^-21 < 0.5 - (2^-18 + delta)/Q.
-                int hi[4], mid[4];
-                v2f fA, fB;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    hi[r] = acc[3][r] * 256 + acc[2][r];
-                    mid[r] = acc[1][r] * 256 + acc[0][r];
-                    const float fv = (float)((hi[r] << 5) + (mid[r] >> 11));
-                    if (r < 2) fA[r] = fv;
-                    else fB[r - 2] = fv;
-                }
-                const float* qf = &s_qf[ct][4 * mt + gq][0];  // sf[4], thr[4] of positions 16mt+4gq..+3
-                const v2f sA = {qf[0], qf[1]}, sB = {qf[2], qf[3]};
-                const v2f M2 = {12582912.0f, 12582912.0f};
-                const v2f zA = fA * sA, zB = fB * sB;
-                const v2f aA = zA + M2, aB = zB + M2;
-                const v2f rA = aA - M2, rB = aB - M2;
-                const v2f dA = zA - rA, dB = zB - rB;
-                const float zz[4] = {zA[0], zA[1], zB[0], zB[1]};
-                const float aa[4] = {aA[0], aA[1], aB[0], aB[1]};
-                const float dd[4] = {dA[0], dA[1], dB[0], dB[1]};
                 uint32_t qb[4];  // low 16 bits = quantised value
-                bool a1[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    qb[r] = __float_as_uint(aa[r]);  // 0x4B400000 + q
-                    a1[r] = !(__builtin_fmaf(__builtin_fabsf(zz[r]), 0x1p-21f, __builtin_fabsf(dd[r])) < qf[4 + r]);
-                    if (mt == 0 && r == 0 && gq == 0) a1[r] = false;  // coefficient 0: overwritten below
-                }
-                if (__any(a1[0] || a1[1] || a1[2] || a1[3])) {
-                    // second look in fp64 with the least significant digit included (wave-uniform, rare)
-                    if (lane == 0) atomicAdd(&sp.stats[0], 1ull);
-                    uint4 t0 = sp.afrag[(mt * kScreenLimbs) * 64 + lane];
-                    v4i acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w}, B,
-                                                                     v4i{0, 0, 0, 0}, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (a1[r]) {
-                            // {s1, thr1, s2, thr2} of this position: read from memory, the second look is rare
-                            // and 4 KiB of LDS are worth more as room for another stream's tail kernels
-                            const double* qc = sp.qconst + ((size_t)ct * 64 + 16 * mt + 4 * gq + r) * 4;
-                            const double y1 = (double)hi[r] * 65536.0 + (double)mid[r];  // exact
-                            const double y2 = y1 * 256.0 + (double)acc0[r];              // exact
-                            if constexpr (STD) {
-                                // standard mode is DEFINED by the fixed-point map: decide exactly in integers
-                                const long long Y = (long long)y2;
-                                const unsigned long long Dq = (unsigned long long)sp.qnat_zz[ct * 64 + 16 * mt + 4 * gq + r] << 39;
-                                const unsigned long long a = (unsigned long long)(Y < 0 ? -Y : Y);
-                                const unsigned long long nn = (2 * a + Dq) / (2 * Dq);
-                                qb[r] = (uint32_t)(Y < 0 ? -(long long)nn : (long long)nn);
-                            } else {
-                                const double z = y2 * qc[2];
-                                const double t = __builtin_fabs(z) + 0.5;
-                                const double fr = t - __builtin_floor(t);
-                                const int nn = (int)t;
-                                qb[r] = (uint32_t)(z < 0.0 ? -nn : nn);
-                                amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
-                            }
-                        }
-                    }
-                }
+                screen_quantise<STD>(A[mt], B, sp, &s_qf[ct][4 * mt + gq][0], ct, mt, gq, lane, qb, amb);
                 // zig-zag positions 16mt+4gq .. +3 of unit 16j+n -> transpose buffer + non-zero bits
                 i16a* row = tb16 + (16 * mt + 4 * gq) * 64 + row_unit_off(16 * j + n);
 #pragma unroll

@@ -145,11 +145,20 @@ struct mi355_jpeg_ctx {
     // screened (integer-MFMA) pipeline
     uint4* d_afrag = nullptr;       // MFMA A fragments of the fixed-point maps (static): [strict, standard]
     double* d_qconst = nullptr;     // [2][64][4] accept thresholds for the current tables
-    float* d_qconst_f = nullptr;    // [2][16][8] fp32 first-look scale factors and thresholds
+    float* d_qconst_f = nullptr;    // [2 maps][2][16][8] fp32 first-look scale factors and thresholds
     uint32_t* d_lut2 = nullptr;     // [2 modes][2][16][64] whole AC symbols for |value| <= 31
     uint32_t* d_counters = nullptr; // [0..7] arena overflow-pool words of the parts of a batch
     unsigned long long* d_stats = nullptr;  // [0] second looks, [1] exact units (mi355_jpeg_screen_stats)
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
+    // single-launch pipeline (jpeg_fused_kernels.hip)
+    int pipeline = 1;               // 1: k_encode_fused (strict and standard 4:4:4); 0: the four-launch pipeline (MI355_JPEG_PIPELINE=legacy; always for 4:2:0)
+    unsigned long long* d_rec = nullptr;
+    size_t rec_cap = 0;             // granules
+    uint32_t* d_ticket = nullptr;   // [2]
+    uint32_t* d_ovf = nullptr;
+    size_t ovf_cap = 0;             // words
+    uint32_t epoch = 0;
+    uint32_t fused_wgs = 256;       // workgroups of k_encode_fused (one per CU)
     uint2* d_meta = nullptr;
     size_t meta_cap = 0;
     uint32_t* d_arena = nullptr;
@@ -241,24 +250,31 @@ int upload_tables(mi355_jpeg_ctx* c) {
             qc[ct][R][3] = tau2 < 0.5 ? 0.5 - tau2 : -1.0;
         }
     HIP_TRY(hipMemcpy(c->d_qconst, qc, sizeof qc, hipMemcpyHostToDevice));
-    // First look in fp32 (k_screen_encode): zf = fl(fl(V) * sf), V = floor(Y1/2^11), sf = fl(2^-20/Q).
-    // |c/Q - V*2^-20/Q| < (2^-18 + delta)/Q (dropped low bits of Y1, digit 0, map error) and
-    // |zf - V*2^-20/Q| <= |z|*2^-22 (three fp32 roundings), the latter covered in the kernel by the
-    // |zf|*2^-21 term; thr = 0.5 - tau - 2^-22 (float rounding of thr itself and of the test).
-    float qf[2][16][8];
-    for (int ct = 0; ct < 2; ++ct)
-        for (int grp = 0; grp < 16; ++grp)
-            for (int r = 0; r < 4; ++r) {
-                const int R = 16 * (grp >> 2) + 4 * (grp & 3) + r;
-                const double Q = (double)(ct ? c->qchrom[zz[R]] : c->qlum[zz[R]]);
-                const double delta = kScreenEps[R] + kScreenFixErr;
-                const double tau = ((std::ldexp(1.0, -18) + delta) / Q * 1.000001) * c->tau_scale + std::ldexp(1.0, -22);
-                qf[ct][grp][r] = (float)(std::ldexp(1.0, -20) / Q);
-                // round the threshold DOWN to float
-                float th = tau < 0.5 ? (float)(0.5 - tau) : -1.0f;
-                if (tau < 0.5 && (double)th > 0.5 - tau) th = std::nextafterf(th, -1.0f);
-                qf[ct][grp][4 + r] = th;
-            }
+    // First look in fp32 (screen_quantise, jpeg_screen_devfn.h): the top three digits give Y' = Lt p / 2^16 without
+    // the two low digits; zf = fl(fma(acc4, 2^16, fl(acc3 * 256 + acc2)) * sf), sf = fl(2^-23/Q).
+    //   |c/Q - Y' 2^-23/Q| <= (E1_R + delta_R)/Q   (dropped digits: exact worst case per row; map + chain error)
+    //   |zf - Y' 2^-23/Q|  <= |z| 2^-22 + 2^-18/Q   (three fp32 roundings; the conversion of acc3 * 256 + acc2)
+    // the first term of the second line is covered in the kernel by |zf| 2^-21; thr = 0.5 - tau - 2^-22 (float
+    // rounding of thr itself and of the test), rounded DOWN to float.  One set per map (strict / standard).
+    float qf[2][2][16][8];
+    for (int m = 0; m < 2; ++m)
+        for (int ct = 0; ct < 2; ++ct)
+            for (int grp = 0; grp < 16; ++grp)
+                for (int r = 0; r < 4; ++r) {
+                    const int R = 16 * (grp >> 2) + 4 * (grp & 3) + r;
+                    const double Q = (double)(ct ? c->qchrom[zz[R]] : c->qlum[zz[R]]);
+                    const auto& limb = m ? kStdLimb : kScreenLimb;
+                    long s1 = 0, s0 = 0;
+                    for (int i = 0; i < 64; ++i) s1 += std::abs((int)limb[1][R][i]), s0 += std::abs((int)limb[0][R][i]);
+                    const double e1 = std::ldexp(128.0 * (256.0 * (double)s1 + (double)s0), -kScreenFracBits);
+                    const double delta = kScreenEps[R] + kScreenFixErr;
+                    const double tau = ((e1 + std::ldexp(1.0, -18) + delta) / Q * 1.000001) * c->tau_scale + std::ldexp(1.0, -22);
+                    qf[m][ct][grp][r] = (float)(std::ldexp(1.0, 16 - kScreenFracBits) / Q);
+                    // round the threshold DOWN to float
+                    float th = tau < 0.5 ? (float)(0.5 - tau) : -1.0f;
+                    if (tau < 0.5 && (double)th > 0.5 - tau) th = std::nextafterf(th, -1.0f);
+                    qf[m][ct][grp][4 + r] = th;
+                }
     HIP_TRY(hipMemcpy(c->d_qconst_f, qf, sizeof qf, hipMemcpyHostToDevice));
     // Whole-symbol tables of the screened pipeline's unit walk: for run r and value v (|v| <= 31)
     // the Huffman code of (r, size(v)) followed by v's value bits, left-aligned in 32 bits, with
@@ -377,7 +393,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     const bool stdm = (g.flags & MI355_F_STANDARD) != 0;
     sp.afrag = c->d_afrag + (stdm ? kAfragBytes / sizeof(uint4) : 0);
     sp.qconst = c->d_qconst;
-    sp.qconst_f = c->d_qconst_f;
+    sp.qconst_f = c->d_qconst_f + (stdm ? 256 : 0);
     sp.qd = c->d_q;
     sp.qnat_zz = c->d_qzz;
     sp.lut = c->d_lut + (stdm ? 1024 : 0);
@@ -554,8 +570,75 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     return MI355_OK;
 }
 
+// Single-launch pipeline: k_encode_fused.  Event slots: [0,1] the kernel; the other slots coincide with 1.
+FusedParams fused_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint32_t wgs, uint8_t* d_out, size_t out_stride,
+                         uint64_t* d_bits, int* err, hipStream_t s) {
+    FusedParams fp;
+    memset(&fp, 0, sizeof fp);
+    *err = MI355_OK;
+    ArenaPlan none{1, 0, 0};
+    fp.sp = screen_params(c, g, n_frames, none, nullptr);
+    fp.sp.prio_from_wg = 0xFFFFFFFFu;
+    int e;
+    const size_t granules = (size_t)g.tiles * n_frames * 4;
+    const bool fresh = granules > c->rec_cap || !c->d_rec;
+    if ((e = ensure(c->d_rec, c->rec_cap, granules, true)) || (e = ensure(c->d_ovf, c->ovf_cap, fused_ovf_words(wgs))) ||
+        (e = ensure(c->d_tile_off, c->tile_off_cap, ((size_t)g.tiles + 1) * n_frames))) {
+        *err = e;
+        return fp;
+    }
+    // every launch tags its granules with a new epoch; records of earlier launches never match.  A fresh
+    // (zeroed) record array can start over; at the wrap the array is cleared in stream order.
+    if (fresh) c->epoch = 0;
+    if (++c->epoch > 0xFFFFu) {
+        if (hipMemsetAsync(c->d_rec, 0, c->rec_cap * sizeof(unsigned long long), s) != hipSuccess) *err = MI355_E_ALLOC;
+        c->epoch = 1;
+    }
+    fp.rec = c->d_rec;
+    fp.ticket = c->d_ticket;
+    fp.epoch = c->epoch;
+    fp.ovf = c->d_ovf;
+    fp.out = d_out;
+    fp.out_stride = out_stride;
+    fp.frame_bits = d_bits;
+    fp.tile_off = c->d_tile_off;
+    return fp;
+}
+
+int run_fused(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t* d_rgb, uint8_t* d_out, size_t out_stride,
+              uint64_t* d_bits, hipStream_t s) {
+    if ((uint64_t)g.tiles * n_frames > 0xFFFFFFF0ull) return MI355_E_ARG;  // 32-bit tickets
+    const uint32_t wgs = fused_grid(g, n_frames, c->fused_wgs);
+    int e;
+    FusedParams fp = fused_params(c, g, n_frames, wgs, d_out, out_stride, d_bits, &e, s);
+    if (e) return e;
+    record(c, 0, s);
+    c->last_launches = 1;
+    HIP_TRY(launch_encode_fused(g, n_frames, d_rgb, fp, false, wgs, s));
+    record(c, 1, s);
+    record(c, 2, s);
+    record(c, 3, s);
+    record(c, 4, s);
+    return MI355_OK;
+}
+
+// Stage probes through the same kernel: coefficients into the tiled workspace layout, samples into d_samples;
+// no output buffer (nothing is written).
+int run_fused_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, uint8_t* d_samples, hipStream_t s) {
+    const uint32_t wgs = fused_grid(g, 1, c->fused_wgs);
+    int e;
+    if ((e = ensure(c->d_bits, c->bits_cap, (size_t)2))) return e;
+    FusedParams fp = fused_params(c, g, 1, wgs, nullptr, 0, c->d_bits + 1, &e, s);
+    if (e) return e;
+    fp.sp.coefs = c->d_coefs;
+    fp.sp.samples = d_samples;
+    HIP_TRY(launch_encode_fused(g, 1, d_rgb, fp, true, wgs, s));
+    return MI355_OK;
+}
+
 // Screened transform only (stage probes): coefficients into the tiled workspace layout.
 int run_screened_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, uint8_t* d_samples, hipStream_t s) {
+    if (c->pipeline == 1 && !is420(g)) return run_fused_probe(c, g, d_rgb, d_samples, s);
     ArenaPlan plan = plan_arena(c, g, 1, unit_count(g) * 54);
     if (plan.total_words > 0xFFFFFFFFull) return MI355_E_ARG;
     int e;
@@ -631,6 +714,9 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     if (ts) c->tau_scale = atof(ts);
     const char* bp = getenv("MI355_JPEG_BATCH_PARTS");
     if (bp && atoi(bp) >= 1 && atoi(bp) <= 8) c->batch_parts = (uint32_t)atoi(bp);
+    const char* pl = getenv("MI355_JPEG_PIPELINE");
+    if (pl && !strcmp(pl, "legacy")) c->pipeline = 0;
+    if (c->n_cus > 0) c->fused_wgs = (uint32_t)c->n_cus;
     const char* sw = getenv("MI355_JPEG_SCREEN_WAVES");
     if (sw && atoi(sw) > 0) c->screen_waves = (uint32_t)atoi(sw);
     int e = MI355_OK;
@@ -640,11 +726,13 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
         hipMalloc((void**)&c->d_status, sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_afrag, 2 * kAfragBytes) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&c->d_qconst_f, 256 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&c->d_qconst_f, 512 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut2, 4096 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_stats, 2 * sizeof(unsigned long long)) != hipSuccess)
+        hipMalloc((void**)&c->d_stats, 2 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&c->d_ticket, 4 * sizeof(uint32_t)) != hipSuccess)
         e = MI355_E_ALLOC;
+    if (!e) e = hip_err(hipMemset(c->d_ticket, 0, 4 * sizeof(uint32_t)));
     if (!e) e = hip_err(hipMemset(c->d_stats, 0, 2 * sizeof(unsigned long long)));
     if (!e) e = hip_err(hipMemset(c->d_status, 0, sizeof(uint32_t)));
     if (!e) e = hip_err(hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t)));
@@ -668,7 +756,7 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
                     c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
                     c->d_counters, c->d_meta,     c->d_arena,  c->d_lut2,     c->d_qconst_f,
-                    c->d_stuff_counts, c->d_stuff_offs, c->d_qzz, c->d_stats};
+                    c->d_stuff_counts, c->d_stuff_offs, c->d_qzz, c->d_stats, c->d_rec, c->d_ticket, c->d_ovf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& es : c->ev_pool)
@@ -722,6 +810,7 @@ int mi355_jpeg_set_huffman(mi355_jpeg_ctx* c, int table, const mi355_huff_table*
 int mi355_jpeg_set_encode_waves(mi355_jpeg_ctx* c, uint32_t waves) {
     if (!c || (waves != 0 && (waves < 32 || waves > 8192 || (waves & 31)))) return MI355_E_ARG;
     c->screen_waves = waves ? waves : (c->n_cus > 0 ? 8u * (uint32_t)c->n_cus : 2048u);
+    c->fused_wgs = c->screen_waves / 8u ? c->screen_waves / 8u : 1u;  // 8 waves per workgroup, one workgroup per CU
     return MI355_OK;
 }
 
@@ -775,6 +864,8 @@ int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t
     if ((flags & MI355_F_STANDARD) && c->transform_mode != 2) return MI355_E_ARG;  // the exact pipeline is strict only
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->transform_mode == 2 && c->pipeline == 1 && !is420(g))
+        return run_fused(c, g, n_frames, (const uint8_t*)d_rgb, (uint8_t*)d_out, out_stride, d_bits, s);
     if (c->transform_mode == 2) {
         // only unit_off / tile arrays of the classic workspace are needed
         if ((e = ensure(c->d_unit_off, c->unit_off_cap, unit_off_words(g) * n_frames))) return e;
