@@ -56,8 +56,9 @@ struct ScreenParams {
 struct FusedParams {
     ScreenParams sp;               // tables, status, stats, probe outputs (meta / arena / counters / tile_bits unused)
     unsigned long long* rec;       // [frames * tiles][4] hand-off granules: {last DCs, scan state, carry word, -}
-    uint32_t* ticket;              // [0] next tile to hand out, [1] waves that have left (both 0 between launches)
+    uint32_t* ticket;              // [frames] next tile of each frame to hand out (zeroed in stream order before every launch)
     uint32_t epoch;                // 1..65535, changes with every launch (tag of this launch's granules)
+    uint32_t debug;                // MI355_JPEG_FUSED_DEBUG (diagnostics only): bit 0 = never wait for other tiles
     uint32_t* ovf;                 // [grid waves][3][54][64] overflow area for strings longer than their LDS slot
     uint8_t* out;                  // frame f at out + f * out_stride (nullptr: stage probes, nothing is written)
     uint64_t out_stride;

@@ -19,11 +19,15 @@
 // No arena, no per-unit metadata, no scan or merge kernel: HBM traffic is the RGB read plus the stream
 // written (plus 32 bytes of hand-off record per tile).
 //
-// Work distribution and forward progress: tiles are handed out by ONE global ticket counter in scan
-// order (frame-major).  A wave only ever waits for tiles with a LOWER ticket, and every ticket that was
-// handed out is held by a wave that is running, so the lowest unfinished tile can always finish -- whatever
-// the dispatch order, the number of resident workgroups or the other kernels on the device
-// (MI355X_MICROARCH.md: nothing may depend on dispatch order or co-residency).  Every spin is bounded and
+// Work distribution and forward progress: the waves are dealt round-robin into G = min(frames, waves)
+// groups; group k takes the frames k, k + G, ... one after the other, and within a frame its waves draw
+// tiles from that frame's ticket counter in scan order.  A wave only ever waits for tiles of the SAME frame
+// with a LOWER ticket, and every ticket that was handed out is held by a wave that is running, so the
+// lowest unfinished tile of every frame can always finish -- whatever the dispatch order, the number of
+// resident workgroups or the other kernels on the device (MI355X_MICROARCH.md: nothing may depend on
+// dispatch order or co-residency).  Per-frame counters keep the pullers per counter few (one counter
+// saturates at ~88 returning atomics per microsecond) and the look-back chains short: a batch of 128
+// frames has 16 waves per frame in flight, so a wave waits for the slowest of 16, not of 2048.  Every spin is bounded and
 // gives up with MI355_E_INTERNAL.  Cross-workgroup data are 8-byte {epoch, payload} granules written by one
 // sc1 store and polled with sc1 loads (per-XCD L2s are not coherent; cdna_hip_programming.md Guideline 16,
 // form R2): the epoch changes with every launch, so stale records of earlier launches never match.
@@ -37,7 +41,7 @@ constexpr uint32_t kFusedWaves = 8;              // waves per workgroup; one wor
 constexpr uint32_t kRowsY = 20, kRowsC = 9;      // words per unit kept in LDS: 640 / 288 bits
 constexpr uint32_t kSlotWave = (kRowsY + 2 * kRowsC + 1) * 64;  // three string slots + one dump row, words
 constexpr uint32_t kWinWords = 64 * 32;          // merge window = the row buffer without its sentinel row
-constexpr uint32_t kSpinLimit = 1u << 21;        // polls (>= ~0.5 us each) before a wait gives up
+constexpr uint32_t kSpinLimit = 1u << 20;        // polls (>= ~0.5 us each) before a wait gives up
 
 __device__ __forceinline__ unsigned long long granule_load(const unsigned long long* p) {
     return __hip_atomic_load((const gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -47,14 +51,18 @@ __device__ __forceinline__ void granule_store(unsigned long long* p, unsigned lo
 }
 
 // Waits until the granule at p (wave-uniform address) carries `epoch`; returns it.  On give-up sets
-// status bit 2 (MI355_E_INTERNAL) and returns a granule with payload 0.
-__device__ __forceinline__ unsigned long long wait_granule(const unsigned long long* p, uint32_t epoch, uint32_t* status) {
+// status bit 2 (MI355_E_INTERNAL), returns a granule with payload 0 and zeroes `limit`: after the first
+// give-up anywhere in the launch (every wave re-reads the status word per tile) no wait spins any more, so a
+// broken launch drains in milliseconds instead of timing out tile after tile.
+__device__ __forceinline__ unsigned long long wait_granule(const unsigned long long* p, uint32_t epoch, uint32_t* status,
+                                                           uint32_t& limit) {
     unsigned long long v = 0;
     for (uint32_t spins = 0;; ++spins) {
         v = granule_load(p);
         if ((uint32_t)(v >> 48) == epoch) break;
-        if (spins > kSpinLimit) {
-            atomicOr(status, 4u);
+        if (spins >= limit) {
+            if (limit) atomicOr(status, 4u);
+            limit = 0;
             v = (unsigned long long)epoch << 48;
             break;
         }
@@ -69,7 +77,7 @@ __device__ __forceinline__ unsigned long long wait_granule(const unsigned long l
 // look-back over their scan granules ({epoch:16, state:2 (1 = total, 2 = inclusive prefix), value:46}).
 // All 64 lanes take part, one predecessor each per round.
 __device__ __forceinline__ unsigned long long tile_lookback(const unsigned long long* rec /* frame's records */, uint32_t tile,
-                                                            uint32_t epoch, uint32_t lane, uint32_t* status) {
+                                                            uint32_t epoch, uint32_t lane, uint32_t* status, uint32_t& limit) {
     constexpr unsigned long long kVal = (1ull << 46) - 1;
     unsigned long long excl = 0;
     int top = (int)tile - 1;  // nearest predecessor not yet accounted for
@@ -88,8 +96,9 @@ __device__ __forceinline__ unsigned long long tile_lookback(const unsigned long 
             const uint32_t upto = firstP < nvalid - 1 ? firstP : nvalid - 1;  // last lane that must have published
             const unsigned long long need = upto >= 63 ? ~0ull : ((2ull << upto) - 1ull);
             if ((bpub & need) == need) break;
-            if (spins > kSpinLimit) {
-                if (lane == 0) atomicOr(status, 4u);
+            if (spins >= limit) {
+                if (limit && lane == 0) atomicOr(status, 4u);
+                limit = 0;
                 return excl;
             }
             __builtin_amdgcn_s_sleep(4);
@@ -182,19 +191,36 @@ __global__ void __launch_bounds__(512, 2)
     __syncthreads();
 
     const uint32_t gwave = blockIdx.x * kFusedWaves + wv;
-    const uint32_t total = g.tiles * n_frames;
+    const uint32_t nwaves = gridDim.x * kFusedWaves;
+    const uint32_t groups = n_frames < nwaves ? n_frames : nwaves;
+    const uint32_t group = gwave % groups;
+    // One frame only: every wave pulls from the same counter.  The workgroup draws its first eight tickets
+    // with one atomic, and when the frame has no more tiles than the grid has waves nobody draws again.
+    const bool wg_draw = groups == 1;
+    const bool single_round = wg_draw && g.tiles <= nwaves;
+    __shared__ uint32_t s_first;
     const uint32_t epoch = fp.epoch;
     uint32_t* const ovf = fp.ovf + (size_t)gwave * 3 * kSlotWordsFull * 64;  // this wave's overflow area
 
-    // ticket = global tile index in scan order (frame-major)
+    uint32_t spin_limit = kSpinLimit;
+    bool first_draw = true;
+    for (uint32_t frame = group; frame < n_frames; frame += groups) {
+    // ticket = tile index inside the frame, in scan order
     uint32_t t;
-    {
+    if (wg_draw && first_draw) {
+        if (tid == 0) s_first = atomicAdd(&fp.ticket[frame], kFusedWaves);
+        __syncthreads();
+        t = s_first + wv;
+    } else {
         uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(fp.ticket, 1u);
+        if (lane == 0) v = atomicAdd(&fp.ticket[frame], 1u);
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     }
-    while (t < total) {
-        const uint32_t frame = t / g.tiles, tile = t - frame * g.tiles;
+    first_draw = false;
+    while (t < g.tiles) {
+        const uint32_t tile = t;
+        // a wait that gave up anywhere poisons the launch: stop waiting (the value is not needed before the merge)
+        const uint32_t poisoned = __hip_atomic_load(sp.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u;
         const uint8_t* f = rgb + (size_t)frame * g.frame_stride;
         unsigned long long* const rec = fp.rec + (size_t)frame * g.tiles * 4;  // this frame's records
         const uint32_t nblk = g.N - tile * 64 < 64u ? g.N - tile * 64 : 64u;   // active blocks of the tile
@@ -360,7 +386,7 @@ __global__ void __launch_bounds__(512, 2)
                 if (lane == 0) {
                     granule_store(rec + (size_t)tile * 4,
                                   ((unsigned long long)epoch << 48) | ((unsigned long long)d2 << 32) | (d1 << 16) | d0);
-                    next_ticket = atomicAdd(fp.ticket, 1u);
+                    next_ticket = single_round ? 0xFFFFFFFFu : atomicAdd(&fp.ticket[frame], 1u);
                 }
             }
 
@@ -391,8 +417,9 @@ __global__ void __launch_bounds__(512, 2)
         int pred[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) pred[c] = __shfl_up(dcv[c], 1);
+        if (poisoned || (fp.debug & 1u)) spin_limit = 0;  // debug bit 0: never wait (timing experiments; output is garbage)
         if (tile > 0 && !restart) {
-            const unsigned long long gdc = wait_granule(rec + (size_t)(tile - 1) * 4, epoch, sp.status);
+            const unsigned long long gdc = wait_granule(rec + (size_t)(tile - 1) * 4, epoch, sp.status, spin_limit);
             if (lane == 0) {
                 pred[0] = (int)(int16_t)(gdc & 0xffffu);
                 pred[1] = (int)(int16_t)((gdc >> 16) & 0xffffu);
@@ -426,7 +453,7 @@ __global__ void __launch_bounds__(512, 2)
             if (lane == 0) granule_store(rec + 1, ((unsigned long long)epoch << 48) | (2ull << 46) | tbits);
         } else {
             if (lane == 0) granule_store(rec + (size_t)tile * 4 + 1, ((unsigned long long)epoch << 48) | (1ull << 46) | tbits);
-            excl = tile_lookback(rec, tile, epoch, lane, sp.status);
+            excl = tile_lookback(rec, tile, epoch, lane, sp.status, spin_limit);
             if (lane == 0)
                 granule_store(rec + (size_t)tile * 4 + 1, ((unsigned long long)epoch << 48) | (2ull << 46) | (excl + tbits));
         }
@@ -449,7 +476,6 @@ __global__ void __launch_bounds__(512, 2)
         const bool tail_shared = !last_tile && ((sb + tbits) & 31u) != 0;  // the last word continues in the next tile
         uint32_t* const outw = reinterpret_cast<uint32_t*>(fp.out + (size_t)frame * fp.out_stride);
         const uint32_t pos0 = sb + incl - blk;                     // this lane's first bit, tile-relative (from word w0)
-        uint32_t carry_out = 0;
 
         for (uint32_t wbase = 0; wbase < nwords; wbase += kWinWords) {  // one round unless the tile is huge
             const uint32_t cnt = nwords - wbase < kWinWords ? nwords - wbase : kWinWords;
@@ -475,32 +501,30 @@ __global__ void __launch_bounds__(512, 2)
                 ap.finish();
             }
             __builtin_amdgcn_wave_barrier();
+            // The word this tile shares with its successor leaves as a carry granule -- BEFORE this tile waits for
+            // its own predecessor's carry (otherwise the carries would form a chain through the whole frame).
+            // It does not depend on the incoming carry unless the whole tile lies inside one word.
+            const bool last_round = wbase + cnt == nwords;
+            const bool carry_late = nwords == 1 && sb != 0;
+            if (last_round && tail_shared && !carry_late && lane == 0)
+                granule_store(rec + (size_t)tile * 4 + 2, ((unsigned long long)epoch << 48) | s_rows[cnt - 1]);
             // the word shared with the previous tile arrives as its carry granule
             if (wbase == 0 && sb != 0) {
-                const unsigned long long gc = wait_granule(rec + (size_t)(tile - 1) * 4 + 2, epoch, sp.status);
+                const unsigned long long gc = wait_granule(rec + (size_t)(tile - 1) * 4 + 2, epoch, sp.status, spin_limit);
                 if (lane == 0) s_rows[0] |= (uint32_t)gc;
                 __builtin_amdgcn_wave_barrier();
             }
-            const bool last_round = wbase + cnt == nwords;
+            if (last_round && tail_shared && carry_late && lane == 0)
+                granule_store(rec + (size_t)tile * 4 + 2, ((unsigned long long)epoch << 48) | s_rows[0]);
             const uint32_t nstore = (last_round && tail_shared) ? cnt - 1 : cnt;
-            if (last_round && tail_shared) carry_out = s_rows[cnt - 1];
             if (fits)
                 for (uint32_t i = lane; i < nstore; i += 64) outw[w0 + wbase + i] = __builtin_bswap32(s_rows[i]);
             __builtin_amdgcn_wave_barrier();
         }
-        if (tail_shared && lane == 0)
-            granule_store(rec + (size_t)tile * 4 + 2, ((unsigned long long)epoch << 48) | carry_out);
         // the row buffer was the window: restore its sentinel row if a (huge) tile reached into it -- it cannot:
         // kWinWords stops short of it -- and go on with the next tile
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_ticket);
     }
-    // the last wave to leave re-arms the ticket for the next launch on this stream
-    if (lane == 0) {
-        const uint32_t done = atomicAdd(fp.ticket + 1, 1u);
-        if (done + 1 == gridDim.x * kFusedWaves) {
-            __hip_atomic_store(fp.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(fp.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 

@@ -302,9 +302,13 @@ struct WaveArena {
 #define MI355_SLOT_ROWS 24
 #endif
 constexpr uint32_t kSlotRows = MI355_SLOT_ROWS;  // words per unit in the LDS slot; larger strings re-walk into global memory
-// Symbol table layout [run][value + 32]: the value-0 column (index 32) is all zero (no-op for
-// exhausted lanes, whatever their run); the unused value -32 column carries ZRL and EOB.
-constexpr uint32_t kLut2Zrl = 15 * 64 + 0;
+// Symbol table layout [value + 32][run] (index (v + 32) * 16 + r): the value-0 row (entries 512..527) is all
+// zero (no-op for exhausted lanes, whatever their run); the unused value -32 row carries ZRL and EOB.
+// Run-minor on purpose: an LDS bank is (index mod 32) = 16 * (v & 1) + r, so lanes that code the same value
+// (on noise 70 % of the symbols are +-1) after different runs read different banks.  The run-major
+// layout of round 1 put every lane with the same value on ONE bank at up to 16 different addresses:
+// that was most of the kernel's LDS bank conflicts.
+constexpr uint32_t kLut2Zrl = 15;
 constexpr uint32_t kLut2Eob = 0;
 
 // Left-aligned 32-bit bit packer.  e = symbol bits left-aligned | length (<= 27) in bits 4..0.
@@ -435,7 +439,7 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
         b.r = run & 15u;
         b.zc = a.v != 0 ? (run >> 4) : 0u;
         b.fast = (uint32_t)(b.v + 31) <= 62u;
-        const uint32_t idx = b.fast ? (b.r * 64u + (uint32_t)(b.v + 32)) : 32u;
+        const uint32_t idx = b.fast ? ((uint32_t)(b.v + 32) * 16u + b.r) : 512u;
         b.e_fast = lut2[idx];
         return b;
     };

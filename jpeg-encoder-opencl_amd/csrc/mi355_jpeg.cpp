@@ -151,10 +151,11 @@ struct mi355_jpeg_ctx {
     unsigned long long* d_stats = nullptr;  // [0] second looks, [1] exact units (mi355_jpeg_screen_stats)
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
     // single-launch pipeline (jpeg_fused_kernels.hip)
-    int pipeline = 1;               // 1: k_encode_fused (strict and standard 4:4:4); 0: the four-launch pipeline (MI355_JPEG_PIPELINE=legacy; always for 4:2:0)
+    int pipeline = 0;               // 0: block-encode kernel + merge kernel; 1 (MI355_JPEG_PIPELINE=fused): the single-launch kernel k_encode_fused (strict and standard 4:4:4)
     unsigned long long* d_rec = nullptr;
     size_t rec_cap = 0;             // granules
-    uint32_t* d_ticket = nullptr;   // [2]
+    uint32_t* d_ticket = nullptr;   // [frames] per-frame ticket counters
+    size_t ticket_cap = 0;
     uint32_t* d_ovf = nullptr;
     size_t ovf_cap = 0;             // words
     uint32_t epoch = 0;
@@ -278,8 +279,9 @@ int upload_tables(mi355_jpeg_ctx* c) {
     HIP_TRY(hipMemcpy(c->d_qconst_f, qf, sizeof qf, hipMemcpyHostToDevice));
     // Whole-symbol tables of the screened pipeline's unit walk: for run r and value v (|v| <= 31)
     // the Huffman code of (r, size(v)) followed by v's value bits, left-aligned in 32 bits, with
-    // the total length in bits 4..0; 0 = the reference has no code.  The value-0 column stays 0 (a
-    // no-op for lanes that ran out of non-zeros); ZRL and EOB live in the unused value -32 column.
+    // the total length in bits 4..0; 0 = the reference has no code.  Layout [v + 32][r] (see
+    // jpeg_screen_devfn.h: LDS banks).  The value-0 row stays 0 (a no-op for lanes that ran out of
+    // non-zeros); ZRL and EOB live in the unused value -32 row.
     std::vector<uint32_t> lut2(2 * 2 * 1024, 0u);
     for (int m = 0; m < 2; ++m)
         for (int ct = 0; ct < 2; ++ct) {
@@ -294,10 +296,10 @@ int upload_tables(mi355_jpeg_ctx* c) {
                     int rs = (r << 4) | size;
                     if (!t.len[rs]) continue;
                     uint32_t vb = (uint32_t)(v < 0 ? v + (1 << size) - 1 : v);
-                    L[r * 64 + v + 32] = entry((t.code[rs] << size) | vb, t.len[rs] + size);
+                    L[(v + 32) * 16 + r] = entry((t.code[rs] << size) | vb, t.len[rs] + size);
                 }
-            L[15 * 64 + 0] = entry(t.code[0xF0], t.len[0xF0]);  // ZRL in the unused value -32 column
-            L[0] = entry(t.code[0x00], t.len[0x00]);            // EOB likewise; column 32 (value 0) stays 0
+            L[15] = entry(t.code[0xF0], t.len[0xF0]);  // ZRL in the unused value -32 row (run 15)
+            L[0] = entry(t.code[0x00], t.len[0x00]);   // EOB likewise (run 0); row 32 (value 0) stays 0
         }
     HIP_TRY(hipMemcpy(c->d_lut2, lut2.data(), lut2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     // copies from pageable memory may return before the DMA has landed; encode calls run on
@@ -583,10 +585,13 @@ FusedParams fused_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, ui
     const size_t granules = (size_t)g.tiles * n_frames * 4;
     const bool fresh = granules > c->rec_cap || !c->d_rec;
     if ((e = ensure(c->d_rec, c->rec_cap, granules, true)) || (e = ensure(c->d_ovf, c->ovf_cap, fused_ovf_words(wgs))) ||
-        (e = ensure(c->d_tile_off, c->tile_off_cap, ((size_t)g.tiles + 1) * n_frames))) {
+        (e = ensure(c->d_tile_off, c->tile_off_cap, ((size_t)g.tiles + 1) * n_frames)) ||
+        (e = ensure(c->d_ticket, c->ticket_cap, ((size_t)n_frames + 3) & ~(size_t)3))) {
         *err = e;
         return fp;
     }
+    // the per-frame ticket counters start from zero in every launch (a memset node in stream order; a multiple of 16 bytes)
+    if (hipMemsetAsync(c->d_ticket, 0, (((size_t)n_frames + 3) & ~(size_t)3) * sizeof(uint32_t), s) != hipSuccess) *err = MI355_E_ALLOC;
     // every launch tags its granules with a new epoch; records of earlier launches never match.  A fresh
     // (zeroed) record array can start over; at the wrap the array is cleared in stream order.
     if (fresh) c->epoch = 0;
@@ -597,6 +602,10 @@ FusedParams fused_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, ui
     fp.rec = c->d_rec;
     fp.ticket = c->d_ticket;
     fp.epoch = c->epoch;
+    {
+        static const char* dbg = getenv("MI355_JPEG_FUSED_DEBUG");
+        fp.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
+    }
     fp.ovf = c->d_ovf;
     fp.out = d_out;
     fp.out_stride = out_stride;
@@ -607,7 +616,6 @@ FusedParams fused_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, ui
 
 int run_fused(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t* d_rgb, uint8_t* d_out, size_t out_stride,
               uint64_t* d_bits, hipStream_t s) {
-    if ((uint64_t)g.tiles * n_frames > 0xFFFFFFF0ull) return MI355_E_ARG;  // 32-bit tickets
     const uint32_t wgs = fused_grid(g, n_frames, c->fused_wgs);
     int e;
     FusedParams fp = fused_params(c, g, n_frames, wgs, d_out, out_stride, d_bits, &e, s);
@@ -715,7 +723,7 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     const char* bp = getenv("MI355_JPEG_BATCH_PARTS");
     if (bp && atoi(bp) >= 1 && atoi(bp) <= 8) c->batch_parts = (uint32_t)atoi(bp);
     const char* pl = getenv("MI355_JPEG_PIPELINE");
-    if (pl && !strcmp(pl, "legacy")) c->pipeline = 0;
+    if (pl) c->pipeline = !strcmp(pl, "fused") ? 1 : 0;
     if (c->n_cus > 0) c->fused_wgs = (uint32_t)c->n_cus;
     const char* sw = getenv("MI355_JPEG_SCREEN_WAVES");
     if (sw && atoi(sw) > 0) c->screen_waves = (uint32_t)atoi(sw);
@@ -729,10 +737,8 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
         hipMalloc((void**)&c->d_qconst_f, 512 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut2, 4096 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_stats, 2 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void**)&c->d_ticket, 4 * sizeof(uint32_t)) != hipSuccess)
+        hipMalloc((void**)&c->d_stats, 2 * sizeof(unsigned long long)) != hipSuccess)
         e = MI355_E_ALLOC;
-    if (!e) e = hip_err(hipMemset(c->d_ticket, 0, 4 * sizeof(uint32_t)));
     if (!e) e = hip_err(hipMemset(c->d_stats, 0, 2 * sizeof(unsigned long long)));
     if (!e) e = hip_err(hipMemset(c->d_status, 0, sizeof(uint32_t)));
     if (!e) e = hip_err(hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t)));

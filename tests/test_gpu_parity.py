@@ -743,3 +743,53 @@ def test_screen_counters_are_exposed(jpeg):
     assert 0 < looks < units // 4          # groups of 16 units; a small share of them
     assert exact < units // 1000
     e2.close()
+
+
+def test_single_launch_pipeline_is_bit_identical(jpeg, monkeypatch):
+    """MI355_JPEG_PIPELINE=fused: the single-launch kernel (block encode + in-kernel look-back scan + merge,
+    jpeg_fused_kernels.hip) against the oracle: ragged sizes, one-tile and many-tile frames, batches (several
+    frames per look-back group and several groups), high quality (strings longer than their LDS slot), the
+    capacity error, and the stage probes through the same kernel."""
+    monkeypatch.setenv("MI355_JPEG_PIPELINE", "fused")
+    e2 = jpeg.Encoder(0)
+    rng = np.random.default_rng(7)
+    for (W, H, q, cds) in [(8, 8, 50, True), (253, 254, 50, True), (640, 360, 50, True), (1000, 37, 90, False),
+                           (1920, 1080, 75, True), (512, 512, 100, False), (24, 4099, 50, True)]:
+        rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8) if (W * H) % 3 else ol.lcg_frame(W, H, 11)
+        ql, qc = set_quality(e2, q)
+        flags = jpeg.F_CDS if cds else 0
+        try:
+            o = ol.oracle_encode(rgb, ql, qc, cds, KEEP)
+        except RuntimeError:
+            with pytest.raises(jpeg.JpegError):
+                e2.encode_scan(rgb, flags)
+            continue
+        bits, nb = e2.encode_scan(rgb, flags)
+        assert nb[0] == o.n_bits, (W, H, q)
+        assert np.array_equal(bits[0], o.bits), (W, H, q)
+        assert np.array_equal(e2.probe_samples(rgb, flags), o.padded), (W, H, q)
+        cf = e2.probe_coefficients(rgb, flags)
+        assert np.array_equal(cf.astype(np.int32), o.zigzag), (W, H, q)
+    # batches: 37 frames (more frames than ... no: fewer than waves -> one group per frame) and a 4K frame
+    ql, qc = set_quality(e2, 50)
+    frames = np.stack([ol.lcg_frame(320, 200, 50 + f) for f in range(37)])
+    bits, nb = e2.encode_scan(frames)
+    for f in range(37):
+        o = ol.oracle_encode(frames[f], ql, qc, True)
+        assert nb[f] == o.n_bits and np.array_equal(bits[f], o.bits), f
+    big = ol.lcg_frame(3840, 2160, 1)
+    bits, nb = e2.encode_scan(big, cap=6 << 20)
+    assert nb[0] == 38227880
+    assert ascii_sha(bits[0], nb[0]) == "6a4a20a6412d6e3bfd878e09875156170ff80a74d7c10c04b52a425e7dbcf009"
+    with pytest.raises(jpeg.JpegError) as ei:
+        e2.encode_scan(big, cap=1 << 20)
+    assert ei.value.status == jpeg.E_CAPACITY
+    # standard 4:4:4 through the same kernel, with restart intervals
+    ql, qc = ol.quant_tables(85)
+    e2.set_quant(ql, qc)
+    rgb = ol.lcg_frame(333, 201, 3)
+    o = ol.oracle_std_encode(rgb, ql, qc)
+    bits, nb = e2.encode_scan(rgb, jpeg.F_STANDARD)
+    assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits)
+    assert e2.encode_jfif(rgb, jpeg.F_STANDARD | jpeg.F_RESTART) == ol.oracle_std_jfif_restart(rgb, ql, qc, subsample=0)
+    e2.close()
