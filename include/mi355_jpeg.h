@@ -200,6 +200,47 @@ int mi355_jpeg_probe_unit_bits(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t
 int mi355_jpeg_entropy_only(mi355_jpeg_ctx *ctx, const int16_t *zigzag, uint32_t n_blocks,
                             uint8_t *out, size_t cap, uint64_t *bits);
 
+/* ---- the reference's stage functions, one by one (utils.hpp:77-137) -----------------------------------
+ * Host images in, host images out, each call = one stage kernel on the GPU between an upload and a download.
+ * NOT the fast path -- mi355_jpeg_encode_scan* fuses all of it and never materialises these intermediates --
+ * but the drop-in for a driver that is written stage by stage like JpegEncoderHost
+ * (OpenCLProject_JpegEncoder.cpp:59-225): same in-place semantics, every intermediate bit-identical to the
+ * reference's.  host/mi355_stage_api.cpp wraps them in the reference's own signatures.
+ * Images: interleaved 3 x u8 per pixel (ppm_t.data) or 3 x double per pixel (ppm_d_t.data), row-major. */
+/* performCSC (utils.cpp:92-110), in place. */
+int mi355_jpeg_stage_csc(mi355_jpeg_ctx *ctx, uint8_t *img, uint32_t W, uint32_t H);
+/* performCDS (utils.cpp:113-141), in place on the UNPADDED image. */
+int mi355_jpeg_stage_cds(mi355_jpeg_ctx *ctx, uint8_t *img, uint32_t W, uint32_t H);
+/* copyToLargerImage (utils.cpp:199-208): src (W x H) into the top-left corner of dst (W8 x H8); the rest of
+ * dst is left as it is, like in the reference. */
+int mi355_jpeg_stage_copy_larger(mi355_jpeg_ctx *ctx, const uint8_t *src, uint32_t W, uint32_t H, uint8_t *dst,
+                                 uint32_t W8, uint32_t H8);
+/* addReversedPadding (utils.cpp:211-233), in place: mirror pad right, then bottom.  MI355_E_ARG when a pad is
+ * wider than the image (the reference indexes out of bounds there). */
+int mi355_jpeg_stage_mirror_pad(mi355_jpeg_ctx *ctx, uint8_t *img, uint32_t W8, uint32_t H8, uint32_t oldW, uint32_t oldH);
+/* copyUIntToDoubleImage (utils.cpp:236-246). */
+int mi355_jpeg_stage_to_double(mi355_jpeg_ctx *ctx, const uint8_t *src, double *dst, uint32_t W, uint32_t H);
+/* substractfromAll (utils.cpp:190-196), in place. */
+int mi355_jpeg_stage_subtract(mi355_jpeg_ctx *ctx, double *img, uint32_t W, uint32_t H, double value);
+/* performDCT (utils.cpp:262-270, 314-348), in place: the ordered in-place fp64 chain per 8x8 block and channel, on
+ * whatever doubles the image holds.  W8, H8 multiples of 8. */
+int mi355_jpeg_stage_dct(mi355_jpeg_ctx *ctx, double *img, uint32_t W8, uint32_t H8);
+/* performQuantization (utils.cpp:454-467), in place, with the tables given ([v][u] like quant_mat_lum). */
+int mi355_jpeg_stage_quantize(mi355_jpeg_ctx *ctx, double *img, uint32_t W8, uint32_t H8, const uint32_t qlum[64],
+                              const uint32_t qchrom[64]);
+/* everyMCUisnow2DArray (utils.cpp:482-498): out = int[3 * N][64], N = W8 * H8 / 64. */
+int mi355_jpeg_stage_blocks(mi355_jpeg_ctx *ctx, const double *img, uint32_t W8, uint32_t H8, int32_t *linear);
+/* performZigZag (utils.cpp:554-558). */
+int mi355_jpeg_stage_zigzag(mi355_jpeg_ctx *ctx, const int32_t *linear, int32_t *zigzag, uint32_t rows);
+/* performRLE (utils.cpp:612-620): row r's flat (run, value) pairs at pairs + 128 * r, counts[r] ints of them
+ * (an even number <= 128, the final (0,0) included). */
+int mi355_jpeg_stage_rle(mi355_jpeg_ctx *ctx, const int32_t *zigzag, uint32_t rows, int32_t *pairs, uint32_t *counts);
+/* HuffmanEncoder (utils.cpp:656-698): DC differences from zigzag[row][0], AC symbols from the pair lists AS
+ * GIVEN (same layout as mi355_jpeg_stage_rle writes).  Packed bits MSB-first; *bits = the length of the string the
+ * reference returns.  A (run, size) the reference has no code for is MI355_E_CATEGORY. */
+int mi355_jpeg_stage_huffman(mi355_jpeg_ctx *ctx, const int32_t *zigzag, const int32_t *pairs, const uint32_t *counts,
+                             uint32_t rows_per_channel, uint8_t *out, size_t cap, uint64_t *bits);
+
 /* ---- either side of the path ---------------------------------
  * Pinned synthetic input, generated in place on the device: frame f gets the
  * bytes s_{k+1} >> 24 of the LCG s <- s*1664525 + 1013904223 with s_0 = seed0 + f. */

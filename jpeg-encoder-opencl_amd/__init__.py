@@ -58,6 +58,10 @@ ABI_SYMBOLS = [
     "mi355_jpeg_pool_set_quant", "mi355_jpeg_pool_set_quality", "mi355_jpeg_pool_encode",
     "mi355_jpeg_set_encode_waves", "mi355_jpeg_wrap_jfif", "mi355_jpeg_scan_bound_flags",
     "mi355_jpeg_last_call_launches", "mi355_jpeg_screen_stats",
+    # the reference's stage functions one by one (host/mi355_stage_api.cpp wraps them in the reference's signatures)
+    "mi355_jpeg_stage_csc", "mi355_jpeg_stage_cds", "mi355_jpeg_stage_copy_larger", "mi355_jpeg_stage_mirror_pad",
+    "mi355_jpeg_stage_to_double", "mi355_jpeg_stage_subtract", "mi355_jpeg_stage_dct", "mi355_jpeg_stage_quantize",
+    "mi355_jpeg_stage_blocks", "mi355_jpeg_stage_zigzag", "mi355_jpeg_stage_rle", "mi355_jpeg_stage_huffman",
 ]
 
 _lib = None

@@ -107,4 +107,20 @@ hipError_t launch_rows_to_coefs(const Geom& g, const int16_t* rows, uint32_t* co
 hipError_t launch_unit_bits(const Geom& g, const uint32_t* unit_off, const uint32_t* tile_bits,
                             uint32_t* out, hipStream_t s);
 
+// stage-by-stage kernels (jpeg_stage_kernels.hip): one per stage function of the reference's interface
+hipError_t launch_stage_csc(uint8_t* img, uint64_t n_px, hipStream_t s);
+hipError_t launch_stage_cds(uint8_t* img, uint32_t W, uint32_t H, hipStream_t s);
+hipError_t launch_stage_copy_larger(const uint8_t* src, uint32_t W, uint32_t H, uint8_t* dst, uint32_t W8, hipStream_t s);
+hipError_t launch_stage_mirror(uint8_t* img, uint32_t W8, uint32_t H8, uint32_t oldW, uint32_t oldH, hipStream_t s);
+hipError_t launch_stage_u8_to_f64(const uint8_t* src, double* dst, uint64_t n, hipStream_t s);
+hipError_t launch_stage_sub(double* img, uint64_t n, double val, hipStream_t s);
+hipError_t launch_stage_dct(double* img, uint32_t W8, uint32_t H8, hipStream_t s);
+hipError_t launch_stage_quant(double* img, uint32_t W8, uint32_t H8, const double* q, hipStream_t s);
+hipError_t launch_stage_blocks(const double* img, uint32_t W8, uint32_t H8, int* lin, hipStream_t s);
+hipError_t launch_stage_zigzag(const int* lin, int* zz, uint64_t rows, hipStream_t s);
+hipError_t launch_stage_rle(const int* zz, uint64_t rows, int* pairs, uint32_t* counts, hipStream_t s);
+hipError_t launch_stage_huffman(const int* zz, const int* pairs, const uint32_t* counts, uint64_t N, const uint32_t* lut,
+                                uint32_t* ubits, uint32_t* inchunk, uint64_t* chunk_sum, uint64_t* total, uint32_t* outw,
+                                uint64_t cap_bits, uint32_t* status, hipStream_t s);
+
 }  // namespace mi355

@@ -150,6 +150,8 @@ struct mi355_jpeg_ctx {
     uint32_t* d_counters = nullptr; // [0..7] arena overflow-pool words of the parts of a batch
     unsigned long long* d_stats = nullptr;  // [0] second looks, [1] exact units (mi355_jpeg_screen_stats)
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
+    uint8_t* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // scratch of the stage-by-stage entry points
+    size_t stage_cap[4] = {0, 0, 0, 0};
     // single-launch pipeline (jpeg_fused_kernels.hip)
     int pipeline = 0;               // 0: block-encode kernel + merge kernel; 1 (MI355_JPEG_PIPELINE=fused): the single-launch kernel k_encode_fused (strict and standard 4:4:4)
     unsigned long long* d_rec = nullptr;
@@ -764,6 +766,8 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
                     c->d_counters, c->d_meta,     c->d_arena,  c->d_lut2,     c->d_qconst_f,
                     c->d_stuff_counts, c->d_stuff_offs, c->d_qzz, c->d_stats, c->d_rec, c->d_ticket, c->d_ovf};
     for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (void* p : c->d_stage)
         if (p) (void)hipFree(p);
     for (auto& es : c->ev_pool)
         for (auto& e : es.e)
@@ -1471,6 +1475,205 @@ int mi355_jpeg_pool_encode(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W, u
     for (auto& jb : jobs)
         if (jb.rc) return jb.rc;
     return MI355_OK;
+}
+
+// ---- the reference's stage functions, one by one ---------------------------------------
+// Host image in, one stage kernel, host image out.  Scratch: two device buffers grown on demand.
+}  // extern "C"
+namespace {
+struct Stage {
+    mi355_jpeg_ctx* c;
+    int e = MI355_OK;
+    explicit Stage(mi355_jpeg_ctx* ctx) : c(ctx) {
+        if (!c) e = MI355_E_ARG;
+        else if (hipSetDevice(c->device) != hipSuccess) e = MI355_E_NO_DEVICE;
+    }
+    void* buf(int which, size_t bytes) {  // device scratch `which` (0..3) of at least `bytes`
+        if (e) return nullptr;
+        if (ensure(c->d_stage[which], c->stage_cap[which], bytes ? bytes : 1)) e = MI355_E_ALLOC;
+        return e ? nullptr : c->d_stage[which];
+    }
+    void up(void* d, const void* h, size_t n) {
+        if (!e && hipMemcpy(d, h, n, hipMemcpyHostToDevice) != hipSuccess) e = MI355_E_HIP - (int)hipGetLastError();
+    }
+    void down(void* h, const void* d, size_t n) {
+        if (!e && hipMemcpy(h, d, n, hipMemcpyDeviceToHost) != hipSuccess) e = MI355_E_HIP - (int)hipGetLastError();
+    }
+    void run(hipError_t le) {
+        if (!e && le != hipSuccess) e = MI355_E_HIP - (int)le;
+    }
+};
+}  // namespace
+extern "C" {
+
+int mi355_jpeg_stage_csc(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W, uint32_t H) {
+    if (!img || !W || !H) return MI355_E_ARG;
+    Stage st(c);
+    const size_t n = (size_t)W * H * 3;
+    uint8_t* d = (uint8_t*)st.buf(0, n);
+    st.up(d, img, n);
+    if (!st.e) st.run(launch_stage_csc(d, (uint64_t)W * H, nullptr));
+    st.down(img, d, n);
+    return st.e;
+}
+
+int mi355_jpeg_stage_cds(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W, uint32_t H) {
+    if (!img || !W || !H) return MI355_E_ARG;
+    Stage st(c);
+    const size_t n = (size_t)W * H * 3;
+    uint8_t* d = (uint8_t*)st.buf(0, n);
+    st.up(d, img, n);
+    if (!st.e && W >= 2 && H >= 2) st.run(launch_stage_cds(d, W, H, nullptr));
+    st.down(img, d, n);
+    return st.e;
+}
+
+int mi355_jpeg_stage_copy_larger(mi355_jpeg_ctx* c, const uint8_t* src, uint32_t W, uint32_t H, uint8_t* dst, uint32_t W8,
+                                 uint32_t H8) {
+    if (!src || !dst || !W || !H || W8 < W || H8 < H) return MI355_E_ARG;
+    Stage st(c);
+    const size_t ns = (size_t)W * H * 3, nd = (size_t)W8 * H8 * 3;
+    uint8_t* ds = (uint8_t*)st.buf(0, ns);
+    uint8_t* dd = (uint8_t*)st.buf(1, nd);
+    st.up(ds, src, ns);
+    st.up(dd, dst, nd);  // what lies outside the copied corner stays as the caller had it
+    if (!st.e) st.run(launch_stage_copy_larger(ds, W, H, dd, W8, nullptr));
+    st.down(dst, dd, nd);
+    return st.e;
+}
+
+int mi355_jpeg_stage_mirror_pad(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W8, uint32_t H8, uint32_t oldW, uint32_t oldH) {
+    if (!img || !oldW || !oldH || W8 < oldW || H8 < oldH) return MI355_E_ARG;
+    if (W8 - oldW > oldW || H8 - oldH > oldH) return MI355_E_ARG;  // the reference underflows `oldWidth - diff` there
+    Stage st(c);
+    const size_t n = (size_t)W8 * H8 * 3;
+    uint8_t* d = (uint8_t*)st.buf(0, n);
+    st.up(d, img, n);
+    if (!st.e) st.run(launch_stage_mirror(d, W8, H8, oldW, oldH, nullptr));
+    st.down(img, d, n);
+    return st.e;
+}
+
+int mi355_jpeg_stage_to_double(mi355_jpeg_ctx* c, const uint8_t* src, double* dst, uint32_t W, uint32_t H) {
+    if (!src || !dst || !W || !H) return MI355_E_ARG;
+    Stage st(c);
+    const size_t n = (size_t)W * H * 3;
+    uint8_t* ds = (uint8_t*)st.buf(0, n);
+    double* dd = (double*)st.buf(1, n * sizeof(double));
+    st.up(ds, src, n);
+    if (!st.e) st.run(launch_stage_u8_to_f64(ds, dd, n, nullptr));
+    st.down(dst, dd, n * sizeof(double));
+    return st.e;
+}
+
+int mi355_jpeg_stage_subtract(mi355_jpeg_ctx* c, double* img, uint32_t W, uint32_t H, double value) {
+    if (!img || !W || !H) return MI355_E_ARG;
+    Stage st(c);
+    const size_t n = (size_t)W * H * 3;
+    double* d = (double*)st.buf(1, n * sizeof(double));
+    st.up(d, img, n * sizeof(double));
+    if (!st.e) st.run(launch_stage_sub(d, n, value, nullptr));
+    st.down(img, d, n * sizeof(double));
+    return st.e;
+}
+
+int mi355_jpeg_stage_dct(mi355_jpeg_ctx* c, double* img, uint32_t W8, uint32_t H8) {
+    if (!img || !W8 || !H8 || (W8 & 7) || (H8 & 7)) return MI355_E_ARG;
+    Stage st(c);
+    const size_t n = (size_t)W8 * H8 * 3;
+    double* d = (double*)st.buf(1, n * sizeof(double));
+    st.up(d, img, n * sizeof(double));
+    if (!st.e) st.run(launch_stage_dct(d, W8, H8, nullptr));
+    st.down(img, d, n * sizeof(double));
+    return st.e;
+}
+
+int mi355_jpeg_stage_quantize(mi355_jpeg_ctx* c, double* img, uint32_t W8, uint32_t H8, const uint32_t qlum[64],
+                              const uint32_t qchrom[64]) {
+    if (!img || !qlum || !qchrom || !W8 || !H8 || (W8 & 7) || (H8 & 7)) return MI355_E_ARG;
+    double q[128];
+    for (int i = 0; i < 64; ++i) {
+        if (!qlum[i] || !qchrom[i]) return MI355_E_TABLE;
+        q[i] = (double)qlum[i], q[64 + i] = (double)qchrom[i];
+    }
+    Stage st(c);
+    const size_t n = (size_t)W8 * H8 * 3;
+    double* d = (double*)st.buf(1, n * sizeof(double));
+    double* dq = (double*)st.buf(2, sizeof q);
+    st.up(d, img, n * sizeof(double));
+    st.up(dq, q, sizeof q);
+    if (!st.e) st.run(launch_stage_quant(d, W8, H8, dq, nullptr));
+    st.down(img, d, n * sizeof(double));
+    return st.e;
+}
+
+int mi355_jpeg_stage_blocks(mi355_jpeg_ctx* c, const double* img, uint32_t W8, uint32_t H8, int32_t* linear) {
+    if (!img || !linear || !W8 || !H8 || (W8 & 7) || (H8 & 7)) return MI355_E_ARG;
+    Stage st(c);
+    const size_t n = (size_t)W8 * H8 * 3;
+    double* d = (double*)st.buf(1, n * sizeof(double));
+    int* dl = (int*)st.buf(0, n * sizeof(int));
+    st.up(d, img, n * sizeof(double));
+    if (!st.e) st.run(launch_stage_blocks(d, W8, H8, dl, nullptr));
+    st.down(linear, dl, n * sizeof(int));
+    return st.e;
+}
+
+int mi355_jpeg_stage_zigzag(mi355_jpeg_ctx* c, const int32_t* linear, int32_t* zigzag, uint32_t rows) {
+    if (!linear || !zigzag || !rows) return MI355_E_ARG;
+    Stage st(c);
+    const size_t n = (size_t)rows * 64 * sizeof(int);
+    int* dl = (int*)st.buf(0, n);
+    int* dz = (int*)st.buf(1, n);
+    st.up(dl, linear, n);
+    if (!st.e) st.run(launch_stage_zigzag(dl, dz, rows, nullptr));
+    st.down(zigzag, dz, n);
+    return st.e;
+}
+
+int mi355_jpeg_stage_rle(mi355_jpeg_ctx* c, const int32_t* zigzag, uint32_t rows, int32_t* pairs, uint32_t* counts) {
+    if (!zigzag || !pairs || !counts || !rows) return MI355_E_ARG;
+    Stage st(c);
+    int* dz = (int*)st.buf(0, (size_t)rows * 64 * sizeof(int));
+    int* dp = (int*)st.buf(1, (size_t)rows * 128 * sizeof(int));
+    uint32_t* dc = (uint32_t*)st.buf(2, (size_t)rows * sizeof(uint32_t));
+    st.up(dz, zigzag, (size_t)rows * 64 * sizeof(int));
+    if (!st.e) st.run(launch_stage_rle(dz, rows, dp, dc, nullptr));
+    st.down(counts, dc, (size_t)rows * sizeof(uint32_t));
+    st.down(pairs, dp, (size_t)rows * 128 * sizeof(int));
+    return st.e;
+}
+
+int mi355_jpeg_stage_huffman(mi355_jpeg_ctx* c, const int32_t* zigzag, const int32_t* pairs, const uint32_t* counts,
+                             uint32_t N, uint8_t* out, size_t cap, uint64_t* bits) {
+    if (!zigzag || !pairs || !counts || !out || !bits || !N) return MI355_E_ARG;
+    const size_t rows = (size_t)N * 3;
+    for (size_t r = 0; r < rows; ++r)
+        if (counts[r] > 128 || (counts[r] & 1)) return MI355_E_ARG;
+    Stage st(c);
+    const size_t chunks = (rows + 1023) / 1024;
+    const size_t out_words = (cap + 3) / 4;
+    int* dz = (int*)st.buf(0, rows * 64 * sizeof(int));
+    int* dp = (int*)st.buf(1, rows * 128 * sizeof(int));
+    // counts | unit bits | in-chunk offsets | chunk sums (u64) | total (u64), then the output words
+    const size_t off_ub = rows * 4, off_ic = off_ub + rows * 4, off_cs = (off_ic + rows * 4 + 7) & ~(size_t)7;
+    const size_t off_tot = off_cs + chunks * 8, off_out = off_tot + 8;
+    uint8_t* dm = (uint8_t*)st.buf(2, off_out + out_words * 4);
+    st.up(dz, zigzag, rows * 64 * sizeof(int));
+    st.up(dp, pairs, rows * 128 * sizeof(int));
+    st.up(dm, counts, rows * 4);
+    if (!st.e && hipMemset(dm + off_out, 0, out_words * 4) != hipSuccess) st.e = MI355_E_ALLOC;
+    if (!st.e)
+        st.run(launch_stage_huffman(dz, dp, (const uint32_t*)dm, N, c->d_lut, (uint32_t*)(dm + off_ub), (uint32_t*)(dm + off_ic),
+                                    (uint64_t*)(dm + off_cs), (uint64_t*)(dm + off_tot), (uint32_t*)(dm + off_out),
+                                    (uint64_t)out_words * 32, c->d_status, nullptr));
+    if (!st.e) st.e = mi355_jpeg_sync(c, nullptr);
+    st.down(bits, dm + off_tot, sizeof(uint64_t));
+    if (st.e) return st.e;
+    const size_t nb = (size_t)((*bits + 7) / 8);
+    if (nb > cap) return MI355_E_CAPACITY;
+    st.down(out, dm + off_out, nb);
+    return st.e;
 }
 
 // ---- measurement ---------------------------------------------------------------

@@ -3,6 +3,14 @@
 //   mi355-jpeg in.ppm out.jpg [-q N] [--mode strict|standard] [--subsample ref420|none|420|444]
 //              [--no-cds] [--device K] [--repeat R] [--bits out.bits]
 //   mi355-jpeg --batch IN_DIR OUT_DIR [-q N] [--mode ...] [--subsample ...]
+//   mi355-jpeg in.ppm out.jpg --stages [--cpu-telemetry FILE]
+//
+// --stages: additionally run the reference's stage sequence stage by stage (JpegEncoderHost with the
+// reference's signature: one GPU kernel per stage function of utils.hpp between an upload and a download) and
+// print its nine CPUTelemetry times; with --cpu-telemetry FILE (nine numbers in microseconds, the fields of
+// CPUTelemetry in declaration order: CSC CDS levelShift DCT Quant TotalCopy zigZag RLE Huffman -- e.g. the
+// reference CPU path's own times) print the reference's "## Speedups: ##" table
+// (OpenCLProject_JpegEncoder.cpp:622-629) for the stage-by-stage path and for the fused path.
 //
 // --batch: every *.ppm of IN_DIR -> OUT_DIR/<name>.jpg.  Runs of files of one size are encoded as one
 // batch through mi355_jpeg_pool_encode (frames sharded over all visible GPUs, no collective),
@@ -132,7 +140,8 @@ static int run_batch(const std::string& in_dir, const std::string& out_dir, int 
 int main(int argc, char** argv) {
     std::string in = "../data/fruit.ppm", out = "../data/fruit.jpg", bits_path;
     int quality = 50, device = 0, repeat = 1, pos = 0;
-    bool cds = true, batch = false, restart = false;
+    bool cds = true, batch = false, restart = false, stages = false;
+    std::string cpu_tel_path;
     std::string mode = "strict", subsample;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -147,6 +156,10 @@ int main(int argc, char** argv) {
             batch = true;
         } else if (a == "--restart") {
             restart = true;
+        } else if (a == "--stages") {
+            stages = true;
+        } else if (a == "--cpu-telemetry" && i + 1 < argc) {
+            cpu_tel_path = argv[++i];
         } else if (a == "--mode" && i + 1 < argc) {
             mode = argv[++i];
         } else if (a == "--subsample" && i + 1 < argc) {
@@ -230,6 +243,50 @@ int main(int argc, char** argv) {
     }
     if (writeJpegFile(out.c_str(), img, cds)) return 1;
     std::cout << "Wrote " << out << std::endl;
+    if (stages && !mode_flags && cds && quality == 50) {
+        // the reference's driver, stage by stage, on a copy (the stage functions work in place)
+        ppm_t copy = img;
+        copy.data = (rgb_pixel_t*)malloc(img.width * img.height * sizeof(rgb_pixel_t));
+        memcpy(copy.data, img.data, img.width * img.height * sizeof(rgb_pixel_t));
+        CPUTelemetry g;
+        const int rc = JpegEncoderHost(copy, &g);
+        free(copy.data);
+        if (rc) return 1;
+        std::cout << "Stage-by-stage scan " << (mi355_last_scan() == scan ? "equals" : "DIFFERS FROM") << " the fused path's scan ("
+                  << mi355_last_scan().size() << " bits)" << std::endl;
+        if (mi355_last_scan() != scan) return 1;
+        if (!cpu_tel_path.empty()) {
+            double c[9];
+            FILE* fp = fopen(cpu_tel_path.c_str(), "r");
+            int n = 0;
+            if (fp) {
+                while (n < 9 && fscanf(fp, "%lf", &c[n]) == 1) ++n;
+                fclose(fp);
+            }
+            if (n != 9) {
+                std::cout << "mi355-jpeg: --cpu-telemetry needs nine numbers" << std::endl;
+                return 1;
+            }
+            const CPUTelemetry cpu = {c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]};
+            // the reference's table (OpenCLProject_JpegEncoder.cpp:622-629), CPU stage time / GPU stage time
+            std::cout << "\n## Speedups: ##" << std::endl;
+            std::cout << "Color conversion: " << cpu.CSCTime / g.CSCTime << std::endl;
+            std::cout << "Chroma subsampling: " << cpu.CDSTime / g.CDSTime << std::endl;
+            std::cout << "Level shifting: " << cpu.levelShiftTime / g.levelShiftTime << std::endl;
+            std::cout << "DCT: " << cpu.DCTTime / g.DCTTime << std::endl;
+            std::cout << "Quantization: " << cpu.QuantTime / g.QuantTime << std::endl;
+            std::cout << "ZigZag: " << cpu.zigZagTime / g.zigZagTime << std::endl;
+            std::cout << "RLE: " << cpu.RLETime / g.RLETime << std::endl;
+            // beyond the reference's table (its OpenCL path stops at RLE)
+            std::cout << "Huffman: " << cpu.HuffmanTime / g.HuffmanTime << std::endl;
+            const double cpu_total = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] + c[8];
+            std::cout << "Whole path, fused kernels (device time): " << cpu_total / tel.totalTime << std::endl;
+            std::cout << "Whole path, fused kernels (wall incl. transfers): " << cpu_total / tel.wallTime << std::endl;
+        }
+    } else if (stages) {
+        std::cout << "mi355-jpeg: --stages runs the reference's own sequence: strict mode, q 50, chroma averaging on" << std::endl;
+        return 2;
+    }
     free(img.data);
     return 0;
 }

@@ -182,6 +182,8 @@ void getNearest8x8ImageSize(size_t width, size_t height, size_t* newWidth, size_
     *newHeight = h8;
 }
 
+mi355_jpeg_ctx* mi355_context() { return ensure_ctx() ? nullptr : g_ctx; }
+
 // ---- encode path -------------------------------------------------------------------------
 int mi355_select(int device, int quality) {
     if (g_ctx) {

@@ -237,6 +237,11 @@ void orc_dct_block(double P[64]) {
         }
 }
 
+/* the same chain on n blocks of 64 doubles, in place (for the tests that sweep millions of blocks) */
+void orc_dct_blocks(double *P, size_t n) {
+    for (size_t i = 0; i < n; ++i) orc_dct_block(P + 64 * i);
+}
+
 /* quirk Q6 (utils.cpp:457-463): correctly rounded divide, then round half away
  * from zero. */
 void orc_quant_block(double P[64], const uint32_t q[64]) {

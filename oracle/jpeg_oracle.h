@@ -63,6 +63,7 @@ void orc_padded_size(size_t W, size_t H, size_t *W8, size_t *H8);
 void orc_pad(const uint8_t *src, size_t W, size_t H, uint8_t *dst, size_t W8, size_t H8);
 /* utils.cpp:314-348 for ONE channel of one block: 64 doubles [y*8+x], in place. */
 void orc_dct_block(double P[64]);
+void orc_dct_blocks(double *P, size_t n);
 /* utils.cpp:457-463 for one block: P[v*8+u] = round(P/q[v*8+u]). */
 void orc_quant_block(double P[64], const uint32_t q[64]);
 /* utils.cpp:572-609 + 656-698 for one unit.  dc_diff already formed.

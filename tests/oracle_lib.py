@@ -69,6 +69,7 @@ def oracle():
         L.orc_jfif_frame.argtypes = [C.c_void_p, C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_size_t]
         L.orc_dct_block.argtypes = [C.c_void_p]
+        L.orc_dct_blocks.argtypes = [C.c_void_p, C.c_size_t]
         L.orc_quant_block.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_csc.argtypes = [C.c_void_p, C.c_size_t]
         L.orc_cds.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]

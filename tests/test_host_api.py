@@ -156,3 +156,142 @@ def test_ppm_reader_accepts_wellformed_headers(tmp_path):
     short.write_bytes(b"P6\n8 8\n255\n" + raster[:100])
     out = subprocess.run([CLI, str(short), str(tmp_path / "o.jpg")], capture_output=True, text=True)
     assert out.returncode == 1 and "Error reading the file" in out.stdout
+
+
+# ---- the reference's own interface, name for name (SURVEY §8b "Caller") ---------------------------------
+REF_HDR = "/root/reference/src/utils.hpp"
+REF_DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_api_driver")
+STAGE_NAMES = ["readPPMImage", "writePPMImage", "removeRedChannel", "performCSC", "performCDS", "getPixelPtr", "getPixel",
+               "getPixelR", "getPixelG", "getPixelB", "setPixelR", "setPixelG", "setPixelB", "copyUIntToDoubleImage",
+               "copyToLargerImage", "getNearest8x8ImageSize", "addReversedPadding", "substractfromAll", "performDCT",
+               "performQuantization", "everyMCUisnow2DArray", "performZigZag", "performRLE", "HuffmanEncoder",
+               "JpegEncoderHost"]
+
+
+def test_host_library_exports_the_reference_stage_functions():
+    """libmi355host.a defines every function of the reference's path under the reference's name (the demangled
+    signatures of the ones with distinctive arguments are checked literally, utils.hpp:77-137)."""
+    subprocess.check_call(["make", "-s", "-C", PKG, "all", "host"])
+    syms = subprocess.check_output(["nm", "-C", "--defined-only", os.path.join(PKG, "host", "libmi355host.a")], text=True)
+    syms = syms.replace("[abi:cxx11]", "")
+    for name in STAGE_NAMES:
+        assert (" T %s(" % name) in syms, name
+    for sig in ["performCSC(PPMimage*)", "performDCT(PPMimage_d*)", "substractfromAll(PPMimage_d*, double)",
+                "performQuantization(PPMimage_d*, unsigned int const (*) [8], unsigned int const (*) [8])",
+                "everyMCUisnow2DArray(PPMimage_d*, int (*) [64])", "performZigZag(int (*) [64], int (*) [64], int)",
+                "performRLE(int (*) [64], std::vector<std::vector<int",
+                "JpegEncoderHost(PPMimage, CPUTelemetry*)", "addReversedPadding(PPMimage*, unsigned long, unsigned long)"]:
+        assert sig in syms, sig
+    # HuffmanEncoder with the reference's three arguments (utils.hpp:137), next to the two-argument short form
+    assert any("HuffmanEncoder(int (*) [64], std::vector<std::vector<int" in l and l.rstrip().endswith("int)")
+               for l in syms.splitlines())
+    # JpegEncoderHost sits in an archive member of its own: a program that defines it itself (the reference's main file) links
+    members = subprocess.check_output(["nm", "-C", "--defined-only", "-A", os.path.join(PKG, "host", "libmi355host.a")], text=True)
+    members = members.replace("[abi:cxx11]", "")
+    owner = [l.split(":")[1] for l in members.splitlines() if " T JpegEncoderHost(" in l]
+    assert owner == ["mi355_driver.o"]
+    assert not any(" T performCSC(" in l and "mi355_driver.o" in l for l in members.splitlines())
+
+
+@pytest.mark.skipif(not os.path.exists(REF_HDR), reason="the reference sources are not present on this machine")
+def test_reference_header_links_against_the_host_library(tmp_path):
+    """A translation unit that #includes the REFERENCE'S utils.hpp in place and calls its stage functions in
+    JpegEncoderHost's order links against libmi355host.a + libmi355jpeg.so (link check, nothing runs)."""
+    subprocess.check_call(["make", "-s", "-C", PKG, "all", "host"])
+    exe = str(tmp_path / "ref_api_driver")
+    subprocess.check_call(["g++", "-std=gnu++17", "-O1", "-w", "-DMI355_USE_REFERENCE_HEADER", "-I/root/reference/src", "-o", exe,
+                           os.path.join(ROOT, "tests", "ref_api_driver.cpp"), os.path.join(PKG, "host", "libmi355host.a"),
+                           "-L" + PKG, "-lmi355jpeg", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    und = subprocess.check_output(["nm", "-C", "--undefined-only", exe], text=True)
+    assert "performCSC" not in und and "HuffmanEncoder" not in und  # resolved from the archive, not left dangling
+    # the same TU against this repo's own header (the form that is built where the reference is absent)
+    subprocess.check_call(["g++", "-std=gnu++17", "-O1", "-w", "-I" + os.path.join(PKG, "host"), "-o", exe + "2",
+                           os.path.join(ROOT, "tests", "ref_api_driver.cpp"), os.path.join(PKG, "host", "libmi355host.a"),
+                           "-L" + PKG, "-lmi355jpeg", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def _write_p6(path, rgb):
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]))
+        f.write(np.ascontiguousarray(rgb, np.uint8).tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["fruit", "lcg_ragged", "lcg_aligned"])
+def test_reference_stage_sequence_on_the_gpu(tmp_path, which):
+    """The driver written against the reference's header (oracle/_ref/ref_api_driver: built in the build container
+    with /root/reference/src/utils.hpp included in place, linked against libmi355host.a) runs the reference's stage
+    functions one by one on the GPU in JpegEncoderHost's order; every intermediate it dumps equals the oracle's:
+    performCSC, performCDS, padding, performDCT (fp64, bit for bit -- SURVEY §8 a2/a11), performQuantization,
+    zig-zag rows, the RLE pair lists, the scan string; JpegEncoderHost fills all nine CPUTelemetry fields."""
+    exe = REF_DRIVER
+    if not os.path.exists(exe):  # no prebuilt driver travelled: build the form against this repo's header
+        exe = str(tmp_path / "ref_api_driver")
+        subprocess.check_call(["g++", "-std=gnu++17", "-O1", "-w", "-I" + os.path.join(PKG, "host"), "-o", exe,
+                               os.path.join(ROOT, "tests", "ref_api_driver.cpp"), os.path.join(PKG, "host", "libmi355host.a"),
+                               "-L" + PKG, "-lmi355jpeg", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    rgb = {"fruit": lambda: ol.read_ppm(os.path.join(GOLD, "fruit.ppm")), "lcg_ragged": lambda: ol.lcg_frame(100, 37, 2),
+           "lcg_aligned": lambda: ol.lcg_frame(256, 64, 5)}[which]()
+    H, W, _ = rgb.shape
+    src = str(tmp_path / "in.ppm")
+    _write_p6(src, rgb)
+    pre = str(tmp_path / "o")
+    out = subprocess.run([exe, src, pre], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    o = ol.oracle_encode(rgb, None, None, True, ol.KEEP_ZIGZAG | ol.KEEP_U8_STAGES | ol.KEEP_DCT)
+    H8, W8 = o.H8, o.W8
+    assert np.array_equal(np.fromfile(pre + ".csc", np.uint8).reshape(H, W, 3), o.csc)
+    assert np.array_equal(np.fromfile(pre + ".cds", np.uint8).reshape(H, W, 3), o.cds)
+    assert np.array_equal(np.fromfile(pre + ".pad", np.uint8).reshape(H8, W8, 3), o.padded)
+    dct = np.fromfile(pre + ".dct", np.float64).reshape(H8, W8, 3)
+    assert np.array_equal(dct.view(np.uint64), o.dct.view(np.uint64)), "performDCT differs in some bit of some double"
+    zz = np.fromfile(pre + ".zigzag", np.int32).reshape(-1, 64)
+    assert np.array_equal(zz, o.zigzag)
+    # performQuantization's image, gathered block-wise in natural order, is the zig-zag array un-zig-zagged
+    quant = np.fromfile(pre + ".quant", np.float64).reshape(H8 // 8, 8, W8 // 8, 8, 3)
+    nat = quant.transpose(4, 0, 2, 1, 3).reshape(-1, 64)            # [chan*N + block][v*8+u]
+    assert np.array_equal(nat[:, ol.zigzag_order()].astype(np.int32), o.zigzag)
+    # RLE pair lists: expand them and compare with the rows (RLEBlockAC, utils.cpp:572-609: always a final (0,0))
+    flat = np.fromfile(pre + ".rle", np.int32)
+    pos = 0
+    for r in range(zz.shape[0]):
+        n = int(flat[pos]); pairs = flat[pos + 1:pos + 1 + n].reshape(-1, 2); pos += 1 + n
+        assert tuple(pairs[-1]) == (0, 0)
+        k = 1
+        row = np.zeros(64, np.int32)
+        for run, val in pairs[:-1]:
+            k += int(run)
+            if val != 0:
+                row[k] = val
+            k += 1
+        assert np.array_equal(row[1:], zz[r, 1:]), r
+    assert pos == flat.size
+    want = "".join(str(b) for b in np.unpackbits(o.bits)[:o.n_bits])
+    assert open(pre + ".scan").read() == want
+    tel = np.fromfile(pre + ".tel", np.float64)
+    assert tel.shape == (9,) and (tel > 0).all()
+
+
+@pytest.mark.gpu
+def test_cli_prints_the_reference_speedup_table(tmp_path):
+    """mi355-jpeg --stages --cpu-telemetry: the reference's '## Speedups: ##' block (OpenCLProject_JpegEncoder.cpp:622-629),
+    CPU stage time / GPU stage time, with the CPU times of the reference path (here: the checker's run of it)."""
+    subprocess.check_call(["make", "-s", "-C", PKG, "all", "host"])
+    rgb = ol.read_ppm(os.path.join(GOLD, "fruit.ppm"))
+    r = ol.ref_encode(rgb) if ol.ref() is not None else ol.oracle_encode(rgb)
+    us = r.stage_us  # CSC, CDS, copy, shift, DCT, quant, zigzag, RLE, huffman
+    cpu = [us[0], us[1], us[3], us[4], us[5], us[2], us[6], us[7], us[8]]  # CPUTelemetry's declaration order
+    tel = str(tmp_path / "cpu.txt")
+    open(tel, "w").write(" ".join("%.3f" % max(v, 0.001) for v in cpu))
+    out = subprocess.run([CLI, os.path.join(GOLD, "fruit.ppm"), str(tmp_path / "f.jpg"), "--stages", "--cpu-telemetry", tel],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:]
+    txt = out.stdout
+    assert "Stage-by-stage scan equals the fused path's scan (307829 bits)" in txt
+    block = txt[txt.index("## Speedups: ##"):]
+    for label in ["Color conversion: ", "Chroma subsampling: ", "Level shifting: ", "DCT: ", "Quantization: ", "ZigZag: ", "RLE: "]:
+        line = [l for l in block.splitlines() if l.startswith(label)]
+        assert len(line) == 1 and float(line[0][len(label):]) > 0, label
+    for label in ["CSC Time MI355X", "CDS Time MI355X", "Total Copy Time MI355X", "Level Shifting Time MI355X", "DCT Time MI355X",
+                  "Quantization Time MI355X", "ZigZag Time MI355X", "RLE Time MI355X", "Huffman Time MI355X", "Total Time MI355X"]:
+        assert label in txt, label

@@ -98,6 +98,11 @@ def limbs_of(x):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "jpeg-encoder-opencl_amd", "csrc", "jpeg_screen_tables.h"))
+    ap.add_argument("--std-out", default=os.path.join(ROOT, "tests", "golden", "std_dct_q39.i64"))
+    args = ap.parse_args()
     M = exact_map()
     Mf = np.array([[float(x) for x in r] for r in M])
     eps_nat = error_bound(Mf)
@@ -171,9 +176,9 @@ def main():
         for k in range(64):
             for l, d in enumerate(limbs_of(int(std[R, k]))):
                 std_limb[l, R, k] = d
-    std.astype("<i8").tofile(os.path.join(ROOT, "tests", "golden", "std_dct_q39.i64"))
+    std.astype("<i8").tofile(args.std_out)
 
-    out = os.path.join(ROOT, "jpeg-encoder-opencl_amd", "csrc", "jpeg_screen_tables.h")
+    out = args.out
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_screen_tables.py -- do not edit.\n")
         f.write("// Fixed-point copy of the exact linear map of the reference's in-place chain\n")
