@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355jpeg.so")
+LIB_PATH = os.environ.get("MI355_JPEG_LIB") or os.path.join(_HERE, "libmi355jpeg.so")  # (override: A/B runs of two builds)
 
 F_CDS = 1
 F_STANDARD = 2  # decodable baseline JPEG (not a behaviour of the reference), see include/mi355_jpeg.h

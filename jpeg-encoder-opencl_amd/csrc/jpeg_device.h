@@ -45,6 +45,7 @@ struct ScreenParams {
     uint32_t* counters;     // [0] overflow-pool words used
     unsigned long long* stats;  // [0] second looks (wave-level groups), [1] units recomputed by the exact chain
     uint32_t prio_from_wg;  // k_screen_encode: workgroups >= this raise their issue priority (0xFFFFFFFF: none)
+    uint32_t stagger;       // k_screen_encode: those workgroups start this many s_sleep(127) (~3.4 us each) late (0: none)
     uint32_t* status;
     uint32_t* tile_bits;    // [frame][tile] bit totals, accumulated with atomics (zero on entry)
     uint32_t* coefs;        // probe output (tiled coefficient layout) or nullptr

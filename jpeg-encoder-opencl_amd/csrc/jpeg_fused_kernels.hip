@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(512, 2)
     __shared__ uint32_t s_mask_all[kFusedWaves][2][64];                // non-zero masks (lo, hi)
     __shared__ float s_qf[2][16][8];      // per group of 4 positions: 2^-23/Q x4, first-look thresholds x4
     __shared__ uint32_t s_act[2][256];    // (run,size) AC tables
-    __shared__ uint32_t s_lut2[2][1024];  // (run,value) symbol tables
+    __shared__ uint32_t s_lut2[2][kLut2Words];  // (value,run) symbol tables
     __shared__ uint32_t s_dc[2][16];      // DC tables
 
     const ScreenParams& sp = fp.sp;
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(512, 2)
     uint32_t* s_mhi = s_mask_all[wv][1];
     i16a* const tb16 = reinterpret_cast<i16a*>(s_rows);
     if (tid < 512) (&s_act[0][0])[tid] = sp.lut[512 + tid];
-    for (uint32_t i = tid; i < 2048; i += 512) (&s_lut2[0][0])[i] = sp.lut2[i];
+    for (uint32_t i = tid; i < 2 * kLut2Words; i += 512) (&s_lut2[0][0])[i] = sp.lut2[i];
     if (tid < 256) (&s_qf[0][0][0])[tid] = sp.qconst_f[tid];
     if (tid < 32) s_dc[tid >> 4][tid & 15] = sp.lut[(tid >> 4) * 256 + (tid & 15)];
     if (lane < 32) s_rows[64 * 32 + lane] = 0;  // sentinel row after zig-zag position 63 (never written again)

@@ -302,14 +302,17 @@ struct WaveArena {
 #define MI355_SLOT_ROWS 24
 #endif
 constexpr uint32_t kSlotRows = MI355_SLOT_ROWS;  // words per unit in the LDS slot; larger strings re-walk into global memory
-// Symbol table layout [value + 32][run] (index (v + 32) * 16 + r): the value-0 row (entries 512..527) is all
-// zero (no-op for exhausted lanes, whatever their run); the unused value -32 row carries ZRL and EOB.
+// Symbol table layout [value + 32][run] (index (v + 32) * 16 + r), values clamped to [-32, 32]: 65 rows of 16
+// entries.  The value-0 row (entries 512..527) is all zero (no-op for exhausted lanes, whatever their run); the
+// rows of -32 and +32 are all zero too ("no whole-symbol entry": larger values are clamped onto them and take the
+// slow path); a 66th row carries ZRL (run 15) and EOB (run 0).
 // Run-minor on purpose: an LDS bank is (index mod 32) = 16 * (v & 1) + r, so lanes that code the same value
 // (on noise 70 % of the symbols are +-1) after different runs read different banks.  The run-major
 // layout of round 1 put every lane with the same value on ONE bank at up to 16 different addresses:
 // that was most of the kernel's LDS bank conflicts.
-constexpr uint32_t kLut2Zrl = 15;
-constexpr uint32_t kLut2Eob = 0;
+constexpr uint32_t kLut2Rows = 66, kLut2Words = kLut2Rows * 16;  // per channel type
+constexpr uint32_t kLut2Zrl = 65 * 16 + 15;
+constexpr uint32_t kLut2Eob = 65 * 16;
 
 // Left-aligned 32-bit bit packer.  e = symbol bits left-aligned | length (<= 27) in bits 4..0.
 // Every put stores the word being filled (a later put to the same word overwrites it).
@@ -394,28 +397,35 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {  // uniform result
 
 struct WalkA {  // stage A result: position of a symbol + its value read in flight
     uint32_t pos;
-    int v;
+    uint32_t u;  // the coefficient as stored: 16 bits, zero-extended
 };
 struct WalkB {  // stage B result: symbol entry read in flight
     uint32_t e_fast;
     uint32_t r;
-    uint32_t zc;
-    int v;
-    bool fast;
+    uint32_t zr;  // zeros in front of the symbol (meaningful only where u != 0)
+    uint32_t u;
 };
+typedef uint16_t __attribute__((may_alias)) u16a;
 
 // row: this lane's unit in the [position][unit] row buffer (row[pos * 64] = coefficient at zig-zag
 // position pos; position 64 = 0, the sentinel); mask: non-zero
 // positions 1..63.  A lane that has run out of non-zeros keeps reading the sentinel: value 0
-// selects the all-zero column of the symbol table, i.e. a no-op put -- no validity bookkeeping.
+// selects the all-zero row of the symbol table, i.e. a no-op put -- no validity bookkeeping.
 // maxcnt: wave-uniform upper bound of the lanes' non-zero counts (wave_max of popcount(mask),
 // formed by the caller with all lanes active: DPP reductions need the full wave).
+// Per symbol on the common path: next set bit of the 64-bit mask, one 16-bit LDS read of the value, one table
+// read with the clamped value (no validity select), one put.  Everything rare hides behind two wave-uniform
+// branches: a table miss with a non-zero value (|v| > 31, or a table with holes) assembles the symbol from the
+// (run, size) table, and a run of 16+ zeros in front of a non-zero emits its ZRLs.  (37 VALU instructions per
+// symbol, 46 in round 1; measured A/B the walk's time did not move: it is not bound by instruction count.  Batches of
+// four symbols per LDS round trip were tried too: 2 % slower.)
 template <bool STD, typename Store>
 __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, const uint32_t* __restrict__ lut2,
                                               const uint32_t* __restrict__ act, Packer32<Store>& pk,
                                               const uint32_t maxcnt) {
     uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
-    uint32_t prev = 0, coded = 0;
+    uint32_t prev = 0;
+    bool bad = false;  // a non-zero coefficient without a code (quirk Q13)
 
     auto stageA = [&]() -> WalkA {
         WalkA a;
@@ -428,28 +438,34 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
         const uint32_t nhi = mlo ? mhi : (mhi & (mhi - 1u));
         mlo = nlo;
         mhi = nhi;
-        a.v = (int)row[a.pos * 64u];
+        a.u = reinterpret_cast<const u16a*>(row)[a.pos * 64u];
         return a;
     };
     auto stageB = [&](const WalkA& a) -> WalkB {
         WalkB b;
         const uint32_t run = a.pos - prev - 1u;
         prev = a.pos;
-        b.v = a.v;
+        b.u = a.u;
         b.r = run & 15u;
-        b.zc = a.v != 0 ? (run >> 4) : 0u;
-        b.fast = (uint32_t)(b.v + 31) <= 62u;
-        const uint32_t idx = b.fast ? ((uint32_t)(b.v + 32) * 16u + b.r) : 512u;
-        b.e_fast = lut2[idx];
+        b.zr = run;
+        // table row = clamp(v, -32, 32) + 32 without sign extension: (u + 32) mod 2^16 is v + 32 for v in [-32, 32] and
+        // something above 64 for every other value, which the minimum sends to row 64 (= +32: an all-zero row)
+        const uint16_t t = (uint16_t)(a.u + 32u);
+        const uint32_t trow = t < 64 ? t : 64;
+        const uint32_t* const lr = lut2 + b.r;
+        b.e_fast = lr[trow * 16u];
         return b;
     };
     auto stageC = [&](const WalkB& b) {
         uint32_t e = b.e_fast;
-        if (!b.fast) e = symbol_slow(b.v, b.r, act);
-        coded += e != 0u ? 1u : 0u;  // every non-zero coefficient must find a code (checked after the loop)
-        if (b.zc) {  // (15,0) at every 16th zero before a later non-zero
+        if (e == 0u && b.u != 0u) {  // no whole-symbol entry: a large value (or a table with holes)
+            e = symbol_slow((int)(int16_t)b.u, b.r, act);
+            bad = bad || e == 0u;
+        }
+        // (15,0) at every 16th zero before a later non-zero (a lane that has run out of non-zeros has e == 0)
+        if (b.zr >= 16u && e != 0u) {
             const uint32_t z = lut2[kLut2Zrl];
-            for (uint32_t i = 0; i < b.zc; ++i) pk.put(z);
+            for (uint32_t i = 0; i < (b.zr >> 4); ++i) pk.put(z);
         }
         pk.put(e);
     };
@@ -482,7 +498,7 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
     // the reference appends EOB ALWAYS (quirk Q8); a standard encoder omits it after coefficient 63
     if (!(STD && (mask >> 63))) pk.put(lut2[kLut2Eob]);
     pk.finish();
-    return coded == (uint32_t)__popcll(mask);  // false: a size category without a code (quirk Q13)
+    return !bad;  // false: a size category without a code (quirk Q13)
 }
 
 // ----------------------------------------------------------------------------

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256, 2)
     __shared__ uint32_t s_mask_all[kEncWaves][2][64];              // non-zero masks (lo, hi)
     __shared__ float s_qf[2][16][8];    // per group of 4 positions: 2^-20/Q x4, first-look thresholds x4
     __shared__ uint32_t s_act[2][256];  // (run,size) AC tables
-    __shared__ uint32_t s_lut2[2][1024];  // (run,value) symbol tables
+    __shared__ uint32_t s_lut2[2][kLut2Words];  // (value,run) symbol tables
     __shared__ uint32_t s_dc[2][16];      // DC tables
 
     const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256, 2)
     for (uint32_t i = tid; i < 512; i += 256) {
         (&s_act[0][0])[i] = sp.lut[512 + i];
     }
-    for (uint32_t i = tid; i < 2048; i += 256) (&s_lut2[0][0])[i] = sp.lut2[i];
+    for (uint32_t i = tid; i < 2 * kLut2Words; i += 256) (&s_lut2[0][0])[i] = sp.lut2[i];
     (&s_qf[0][0][0])[tid] = sp.qconst_f[tid];
     if (tid < 32) s_dc[tid >> 4][tid & 15] = sp.lut[(tid >> 4) * 256 + (tid & 15)];
     if (lane < 32) s_tbuf[64 * 32 + lane] = 0;  // sentinel row after zig-zag position 63 (never written again)
@@ -96,6 +96,11 @@ __global__ void __launch_bounds__(256, 2)
     const uint32_t pstart = xcd_map ? local : gwave;
     const uint32_t pstep = xcd_map ? local_n : gridDim.x * kEncWaves;
 
+    // Stagger (MI355X_MICROARCH.md, two waves per SIMD, item 9): the two workgroups of a CU otherwise run in lockstep --
+    // both waves of a SIMD in the issue-heavy transform, then both in the latency-bound walk.  Starting the
+    // later-dispatched workgroup about half a pass late puts one wave's walk beside the other's transform.
+    if (blockIdx.x >= sp.prio_from_wg)
+        for (uint32_t i = 0; i < sp.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     WaveArena wa{gwave * sp.region_words, sp.region_words};
 #ifdef MI355_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev, wave_t0, wave_t1;

@@ -146,7 +146,7 @@ struct mi355_jpeg_ctx {
     uint4* d_afrag = nullptr;       // MFMA A fragments of the fixed-point maps (static): [strict, standard]
     double* d_qconst = nullptr;     // [2][64][4] accept thresholds for the current tables
     float* d_qconst_f = nullptr;    // [2 maps][2][16][8] fp32 first-look scale factors and thresholds
-    uint32_t* d_lut2 = nullptr;     // [2 modes][2][16][64] whole AC symbols for |value| <= 31
+    uint32_t* d_lut2 = nullptr;     // [2 modes][2][66][16] whole AC symbols for |value| <= 31
     uint32_t* d_counters = nullptr; // [0..7] arena overflow-pool words of the parts of a batch
     unsigned long long* d_stats = nullptr;  // [0] second looks, [1] exact units (mi355_jpeg_screen_stats)
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
@@ -284,11 +284,12 @@ int upload_tables(mi355_jpeg_ctx* c) {
     // the total length in bits 4..0; 0 = the reference has no code.  Layout [v + 32][r] (see
     // jpeg_screen_devfn.h: LDS banks).  The value-0 row stays 0 (a no-op for lanes that ran out of
     // non-zeros); ZRL and EOB live in the unused value -32 row.
-    std::vector<uint32_t> lut2(2 * 2 * 1024, 0u);
+    constexpr size_t kL2 = 66 * 16;  // kLut2Words (jpeg_screen_devfn.h)
+    std::vector<uint32_t> lut2(2 * 2 * kL2, 0u);
     for (int m = 0; m < 2; ++m)
         for (int ct = 0; ct < 2; ++ct) {
             const mi355_huff_table& t = m ? c->huff_std[2 + ct] : c->huff[2 + ct];
-            uint32_t* L = &lut2[(size_t)(m * 2 + ct) * 1024];
+            uint32_t* L = &lut2[(size_t)(m * 2 + ct) * kL2];
             auto entry = [&](uint32_t bits, int len) -> uint32_t { return len ? ((bits << (32 - len)) | (uint32_t)len) : 0u; };
             for (int r = 0; r < 16; ++r)
                 for (int v = -31; v <= 31; ++v) {
@@ -300,8 +301,9 @@ int upload_tables(mi355_jpeg_ctx* c) {
                     uint32_t vb = (uint32_t)(v < 0 ? v + (1 << size) - 1 : v);
                     L[(v + 32) * 16 + r] = entry((t.code[rs] << size) | vb, t.len[rs] + size);
                 }
-            L[15] = entry(t.code[0xF0], t.len[0xF0]);  // ZRL in the unused value -32 row (run 15)
-            L[0] = entry(t.code[0x00], t.len[0x00]);   // EOB likewise (run 0); row 32 (value 0) stays 0
+            // rows 0 (-32), 32 (0) and 64 (+32) stay zero; ZRL and EOB live in row 65
+            L[65 * 16 + 15] = entry(t.code[0xF0], t.len[0xF0]);
+            L[65 * 16] = entry(t.code[0x00], t.len[0x00]);
         }
     HIP_TRY(hipMemcpy(c->d_lut2, lut2.data(), lut2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     // copies from pageable memory may return before the DMA has landed; encode calls run on
@@ -392,6 +394,10 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     const size_t arena_words = plan.total_words;
     // the later-dispatched half of a launch that fills the device two workgroups per CU (see the kernel)
     sp.prio_from_wg = (c->n_cus > 0 && plan.grid / 4 == 2u * (uint32_t)c->n_cus) ? (uint32_t)c->n_cus : 0xFFFFFFFFu;
+    {
+        static const char* stg = getenv("MI355_JPEG_STAGGER");
+        sp.stagger = stg ? (uint32_t)atoi(stg) : 0u;
+    }
     sp.region_words = plan.region_words;
     sp.overflow_base = plan.grid * plan.region_words;
     const bool stdm = (g.flags & MI355_F_STANDARD) != 0;
@@ -401,7 +407,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.qd = c->d_q;
     sp.qnat_zz = c->d_qzz;
     sp.lut = c->d_lut + (stdm ? 1024 : 0);
-    sp.lut2 = c->d_lut2 + (stdm ? 2048 : 0);
+    sp.lut2 = c->d_lut2 + (stdm ? 2 * 66 * 16 : 0);
     sp.meta = c->d_meta;
     sp.arena = c->d_arena;
     sp.arena_words = (uint32_t)(arena_words > 0xFFFFFFFFull ? 0xFFFFFFFFull : arena_words);
@@ -737,7 +743,7 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
         hipMalloc((void**)&c->d_afrag, 2 * kAfragBytes) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst_f, 512 * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&c->d_lut2, 4096 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->d_lut2, 4 * 66 * 16 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_stats, 2 * sizeof(unsigned long long)) != hipSuccess)
         e = MI355_E_ALLOC;

@@ -793,3 +793,95 @@ def test_single_launch_pipeline_is_bit_identical(jpeg, monkeypatch):
     assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits)
     assert e2.encode_jfif(rgb, jpeg.F_STANDARD | jpeg.F_RESTART) == ol.oracle_std_jfif_restart(rgb, ql, qc, subsample=0)
     e2.close()
+
+
+def _golden(W, H, q):
+    return {c["seed"]: (c["n_bits"], c["sha256_ascii_bits"]) for c in CASES
+            if c.get("W") == W and c.get("H") == H and c.get("quality") == q and c.get("cds_on") and "seed" in c}
+
+
+def test_config3_full_batch_of_1024_1080p_frames_q75(jpeg):
+    """configs[2] at its full size: 1024 frames 1920x1080 (LCG seeds 1..1024, generated on the device), q=75, ONE
+    call.  Every frame's bit count is plausible, the frames the reference build pinned (seeds 1, 2, 513, 1024: SHA-256
+    of the scan string) match, three more sampled frames equal the oracle, and the call equals a second call on a
+    sub-batch (parts and batch position do not change a frame's bits)."""
+    import torch
+    n, W, H = 1024, 1920, 1080
+    dev = torch.device("cuda", 0)
+    e2 = jpeg.Encoder(0)
+    ql, qc = set_quality(e2, 75)
+    d_rgb = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    e2.synth_lcg_device(d_rgb.data_ptr(), W * H * 3, n, 1)
+    cap = 3 << 20
+    d_out = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
+    d_bits = torch.zeros(n, dtype=torch.int64, device=dev)
+    e2.encode_scan_device(d_rgb.data_ptr(), W, H, n, d_out.data_ptr(), cap, d_bits.data_ptr())
+    e2.sync()
+    bits = d_bits.cpu().numpy()
+    assert (bits > 15_500_000).all() and (bits < 16_200_000).all()      # noise at q75: ~7.64 bit/px, every frame
+    gold = _golden(W, H, 75)
+    assert set(gold) >= {1, 2, 513, 1024}
+    for seed, (nb, sha) in gold.items():
+        f = seed - 1
+        assert int(bits[f]) == nb, seed
+        assert ascii_sha(d_out[f, :(nb + 7) // 8].cpu().numpy(), nb) == sha, seed
+    for f in (100, 777, 1000):
+        frame = d_rgb[f].cpu().numpy()
+        assert np.array_equal(frame, ol.lcg_frame(W, H, 1 + f))          # the device generator
+        o = ol.oracle_encode(frame, ql, qc, True)
+        assert int(bits[f]) == o.n_bits and np.array_equal(d_out[f, :(o.n_bits + 7) // 8].cpu().numpy(), o.bits), f
+    # a sub-batch on its own gives the same bytes
+    d_out2 = torch.zeros((8, cap), dtype=torch.uint8, device=dev)
+    d_bits2 = torch.zeros(8, dtype=torch.int64, device=dev)
+    e2.encode_scan_device(d_rgb[500:508].data_ptr(), W, H, 8, d_out2.data_ptr(), cap, d_bits2.data_ptr())
+    e2.sync()
+    assert torch.equal(d_bits2, d_bits[500:508]) and torch.equal(d_out2, d_out[500:508])
+    e2.close()
+
+
+def test_config4_per_gpu_share_1024_4k_frames_through_the_pool(jpeg):
+    """configs[3], the share of one GPU: 1024 frames 3840x2160 (LCG seeds 1..1024) from host memory through
+    mi355_jpeg_pool_encode over every visible device (device_ids = NULL; on the 8-GPU node the same call shards 8192
+    frames), q=50.  All bit counts plausible, the eleven frames the reference build pinned match by SHA-256, and
+    sampled frames equal the device-resident single-frame path byte for byte."""
+    import ctypes as C
+    import torch
+    n, W, H = 1024, 3840, 2160
+    dev = torch.device("cuda", 0)
+    e2 = jpeg.Encoder(0)
+    set_quality(e2, 50)
+    h_rgb = torch.empty((n, H, W, 3), dtype=torch.uint8)                 # 25.5 GB of host memory (registered by the pool)
+    step = 64
+    d_tmp = torch.empty((step, H, W, 3), dtype=torch.uint8, device=dev)
+    for lo in range(0, n, step):
+        e2.synth_lcg_device(d_tmp.data_ptr(), W * H * 3, step, 1 + lo)
+        e2.sync()
+        h_rgb[lo:lo + step].copy_(d_tmp)
+    cap = 5 << 20
+    h_out = torch.zeros((n, cap), dtype=torch.uint8)
+    bits = (C.c_uint64 * n)()
+    secs = C.c_double()
+    pool = jpeg.Pool(None)
+    assert pool.workers == jpeg.device_count()
+    pool.set_quality(50)
+    rc = jpeg.lib().mi355_jpeg_pool_encode(pool._h, h_rgb.data_ptr(), W, H, n, jpeg.F_DEFAULT, h_out.data_ptr(), cap, bits, C.byref(secs))
+    pool.close()
+    assert rc == 0, rc
+    nb = np.array(list(bits), np.int64)
+    assert (nb > 38_100_000).all() and (nb < 38_350_000).all()          # noise at q50: ~4.61 bit/px
+    gold = _golden(W, H, 50)
+    assert len(gold) >= 11
+    for seed, (want, sha) in gold.items():
+        f = seed - 1
+        assert int(nb[f]) == want, seed
+        assert ascii_sha(h_out[f, :(want + 7) // 8].numpy(), want) == sha, seed
+    d_out = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    d_bits = torch.zeros(1, dtype=torch.int64, device=dev)
+    for f in (77, 600, 1023):
+        d_tmp[0].copy_(h_rgb[f])
+        e2.encode_scan_device(d_tmp.data_ptr(), W, H, 1, d_out.data_ptr(), cap, d_bits.data_ptr())
+        e2.sync()
+        k = (int(d_bits[0]) + 7) // 8
+        assert int(d_bits[0]) == int(nb[f]) and torch.equal(d_out[:k].cpu(), h_out[f, :k]), f
+    print("pool: %d x 4K in %.3f s = %.1f Gpixel/s incl. PCIe" % (n, secs.value, n * W * H / secs.value / 1e9))
+    e2.close()
