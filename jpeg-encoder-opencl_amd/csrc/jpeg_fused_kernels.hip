@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(512, 2)
     uint32_t* const ovf = fp.ovf + (size_t)gwave * 3 * kSlotWordsFull * 64;  // this wave's overflow area
 
     uint32_t spin_limit = kSpinLimit;
+    bool walk_general[2] = {false, false};  // per channel type: the last pass had a symbol-table miss (walk_nonzeros)
     bool first_draw = true;
     for (uint32_t frame = group; frame < n_frames; frame += groups) {
     // ticket = tile index inside the frame, in scan order
@@ -362,8 +363,8 @@ __global__ void __launch_bounds__(512, 2)
                                     &s_mlo[ul], &s_mhi[ul], lane);
                 }
             }
-            const i16a* row16 = tb16 + row_unit_off(lane);
-            const unsigned long long mask = ((unsigned long long)s_mhi[lane] << 32 | s_mlo[lane]) & ~1ull;
+            i16a* const row16 = tb16 + row_unit_off(lane);
+            unsigned long long mask = ((unsigned long long)s_mhi[lane] << 32 | s_mlo[lane]) & ~1ull;
             const int dc = (int)row16[0];
 
             if constexpr (PROBE) {
@@ -391,8 +392,9 @@ __global__ void __launch_bounds__(512, 2)
             }
 
             Packer32<StoreLds> pkr(StoreLds{slot + lane, slot_rows, (kRowsY + 2 * kRowsC) * 64u - slot_off});
+            mask = mark_zero_runs(row16, mask);  // ZRL positions become virtual non-zeros (after the probe dump above)
             const uint32_t maxcnt = wave_max((uint32_t)__popcll(mask));
-            const bool ok = walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pkr, maxcnt);
+            const bool ok = walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pkr, maxcnt, walk_general[ct]);
             const uint32_t aclen = pkr.bits();
             const bool oversize = active && pkr.words() > slot_rows;
             if (!ok && active) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
@@ -400,7 +402,8 @@ __global__ void __launch_bounds__(512, 2)
             if (ovm) {  // rare: a string longer than its slot: walk again, straight to this wave's overflow area
                 if (oversize) {
                     Packer32<StoreOvf> pg(StoreOvf{ovf + (size_t)chan * kSlotWordsFull * 64 + lane});
-                    (void)walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pg, maxcnt);
+                    bool gen = true;
+                    (void)walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pg, maxcnt, gen);
                 }
             }
             const uint32_t stv = active ? ((aclen << 16) | ((uint32_t)dc & 0xffffu)) : 0u;

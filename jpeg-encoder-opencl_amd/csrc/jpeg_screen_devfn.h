@@ -335,6 +335,7 @@ struct Packer32 {
         n = n2 & 31u;
     }
     __device__ __forceinline__ void finish() { st(w, acc); }
+    __device__ __forceinline__ void reset() { acc = 0, n = 0, w = 0; }
     __device__ __forceinline__ uint32_t bits() const { return w * 32u + n; }
     __device__ __forceinline__ uint32_t words() const { return w + (n ? 1u : 0u); }
 };
@@ -402,99 +403,121 @@ struct WalkA {  // stage A result: position of a symbol + its value read in flig
 struct WalkB {  // stage B result: symbol entry read in flight
     uint32_t e_fast;
     uint32_t r;
-    uint32_t zr;  // zeros in front of the symbol (meaningful only where u != 0)
     uint32_t u;
 };
 typedef uint16_t __attribute__((may_alias)) u16a;
 
+// ZRLs without a branch in the walk.  The reference emits (15,0) at every 16th zero of a run that ends in a non-zero
+// (RLEBlockAC, utils.cpp:586-596).  Those positions -- prev + 16, prev + 32, ... below the next non-zero -- are made
+// "virtual non-zeros" before the walk: their bit is set in the walk mask and a marker value that no coefficient can
+// have (AC categories end at 10 bits) is written into the (otherwise dead) row buffer, so the walk visits them like
+// any symbol, selects the ZRL code for the marker, and every run it ever sees is below 16.  Finding them is a short
+// wave-uniform loop of 64-bit bit tricks: one round per ZRL of the unit that has the most (none in 99 % of the luma
+// units of noise, one or two in a third of the chroma units); one cheap round when there is nothing to do.
+// All lanes must be active.  Returns the walk mask (bit 0 clear).
+constexpr uint32_t kZrlMarker = 0x7FFFu;
+__device__ __forceinline__ uint64_t mark_zero_runs(i16a* row, uint64_t mask) {
+    uint64_t x = mask | 1ull;  // position 0 counts as the start of the first run
+    for (;;) {
+        uint64_t y = x;  // bit q of y: x has a bit in [q - 15, q]
+        y |= y << 1;
+        y |= y << 2;
+        y |= y << 4;
+        y |= y << 8;
+        const uint64_t f = x & ~(y << 1) & ~1ull;  // non-zeros (real or virtual) with 16+ zeros in front
+        if (!__any(f != 0)) break;
+        if (f != 0) {
+            const uint32_t q = (uint32_t)__builtin_ctzll(f);
+            const uint32_t p = 63u - (uint32_t)__builtin_clzll(x & ((1ull << q) - 1ull));  // the non-zero before the run
+            const uint32_t ins = p + 16u;                                                   // < q
+            x |= 1ull << ins;
+            row[ins * 64u] = (int16_t)kZrlMarker;
+        }
+    }
+    return x & ~1ull;
+}
+
 // row: this lane's unit in the [position][unit] row buffer (row[pos * 64] = coefficient at zig-zag
-// position pos; position 64 = 0, the sentinel); mask: non-zero
-// positions 1..63.  A lane that has run out of non-zeros keeps reading the sentinel: value 0
+// position pos; position 64 = 0, the sentinel); mask: the walk mask from mark_zero_runs (non-zero positions 1..63 plus
+// the ZRL markers).  A lane that has run out of non-zeros keeps reading the sentinel: value 0
 // selects the all-zero row of the symbol table, i.e. a no-op put -- no validity bookkeeping.
-// maxcnt: wave-uniform upper bound of the lanes' non-zero counts (wave_max of popcount(mask),
+// maxcnt: wave-uniform upper bound of the lanes' mask populations (wave_max of popcount(mask),
 // formed by the caller with all lanes active: DPP reductions need the full wave).
-// Per symbol on the common path: next set bit of the 64-bit mask, one 16-bit LDS read of the value, one table
-// read with the clamped value (no validity select), one put.  Everything rare hides behind two wave-uniform
-// branches: a table miss with a non-zero value (|v| > 31, or a table with holes) assembles the symbol from the
-// (run, size) table, and a run of 16+ zeros in front of a non-zero emits its ZRLs.  (37 VALU instructions per
-// symbol, 46 in round 1; measured A/B the walk's time did not move: it is not bound by instruction count.  Batches of
-// four symbols per LDS round trip were tried too: 2 % slower.)
+// Per symbol: next set bit of the 64-bit mask, one 16-bit LDS read of the value, one table read with the clamped
+// value (no validity select), the marker select, one put -- and NO branch: in-kernel experiments showed the walk bound
+// by its two exec-masked branches per symbol (rare-path tests), not by its VALU count or its LDS round trips.  A table
+// miss on a real value (|v| > 31, or a table with holes) is only recorded; if any lane had one, the wave walks the
+// pass again with the general loop, and `general` (wave-uniform, kept by the caller per channel type) makes it start
+// there next time -- noise at q = 90 lives in the general loop, q = 50 never sees it.
 template <bool STD, typename Store>
 __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, const uint32_t* __restrict__ lut2,
                                               const uint32_t* __restrict__ act, Packer32<Store>& pk,
-                                              const uint32_t maxcnt) {
-    uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
-    uint32_t prev = 0;
+                                              const uint32_t maxcnt, bool& general) {
+    const u16a* const rowu = reinterpret_cast<const u16a*>(row);
+    const uint32_t zrl = lut2[kLut2Zrl];
     bool bad = false;  // a non-zero coefficient without a code (quirk Q13)
-
-    auto stageA = [&]() -> WalkA {
-        WalkA a;
-        const uint32_t plo = (uint32_t)(__ffs((int)mlo) - 1);  // 0xFFFFFFFF when mlo == 0
-        uint32_t phi = (uint32_t)(__ffs((int)mhi) - 1);        // 0xFFFFFFFF when mhi == 0
-        phi = (phi < 32u ? phi : 32u) + 32u;                   // ... -> 64 = the sentinel slot
-        a.pos = plo < phi ? plo : phi;
-        // clear the lowest set bit of the 64-bit mask
-        const uint32_t nlo = mlo & (mlo - 1u);
-        const uint32_t nhi = mlo ? mhi : (mhi & (mhi - 1u));
-        mlo = nlo;
-        mhi = nhi;
-        a.u = reinterpret_cast<const u16a*>(row)[a.pos * 64u];
-        return a;
-    };
-    auto stageB = [&](const WalkA& a) -> WalkB {
-        WalkB b;
-        const uint32_t run = a.pos - prev - 1u;
-        prev = a.pos;
-        b.u = a.u;
-        b.r = run & 15u;
-        b.zr = run;
-        // table row = clamp(v, -32, 32) + 32 without sign extension: (u + 32) mod 2^16 is v + 32 for v in [-32, 32] and
-        // something above 64 for every other value, which the minimum sends to row 64 (= +32: an all-zero row)
-        const uint16_t t = (uint16_t)(a.u + 32u);
-        const uint32_t trow = t < 64 ? t : 64;
-        const uint32_t* const lr = lut2 + b.r;
-        b.e_fast = lr[trow * 16u];
-        return b;
-    };
-    auto stageC = [&](const WalkB& b) {
-        uint32_t e = b.e_fast;
-        if (e == 0u && b.u != 0u) {  // no whole-symbol entry: a large value (or a table with holes)
-            e = symbol_slow((int)(int16_t)b.u, b.r, act);
-            bad = bad || e == 0u;
+    for (;;) {
+        uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+        uint32_t prev = 0, miss = 0;
+        auto stageA = [&]() -> WalkA {
+            WalkA a;
+            const uint32_t plo = (uint32_t)(__ffs((int)mlo) - 1);  // 0xFFFFFFFF when mlo == 0
+            uint32_t phi = (uint32_t)(__ffs((int)mhi) - 1);        // 0xFFFFFFFF when mhi == 0
+            phi = (phi < 32u ? phi : 32u) + 32u;                   // ... -> 64 = the sentinel slot
+            a.pos = plo < phi ? plo : phi;
+            // clear the lowest set bit of the 64-bit mask
+            const uint32_t nlo = mlo & (mlo - 1u);
+            const uint32_t nhi = mlo ? mhi : (mhi & (mhi - 1u));
+            mlo = nlo;
+            mhi = nhi;
+            a.u = rowu[a.pos * 64u];
+            return a;
+        };
+        auto stageB = [&](const WalkA& a) -> WalkB {
+            WalkB b;
+            const uint32_t run = a.pos - prev - 1u;  // < 16 for every real symbol and every marker
+            prev = a.pos;
+            b.u = a.u;
+            b.r = run & 15u;
+            // table row = clamp(v, -32, 32) + 32 without sign extension: (u + 32) mod 2^16 is v + 32 for v in [-32, 32] and
+            // something above 64 for every other value, which the minimum sends to row 64 (= +32: an all-zero row)
+            const uint16_t t = (uint16_t)(a.u + 32u);
+            const uint32_t trow = t < 64 ? t : 64;
+            const uint32_t* const lr = lut2 + b.r;
+            b.e_fast = lr[trow * 16u];
+            return b;
+        };
+        auto stageC = [&](const WalkB& b) {
+            uint32_t e = b.u == kZrlMarker ? zrl : b.e_fast;
+            if (general) {
+                if (e == 0u && b.u != 0u) {  // no whole-symbol entry: a large value (or a table with holes)
+                    e = symbol_slow((int)(int16_t)b.u, b.r, act);
+                    bad = bad || e == 0u;
+                }
+            } else {
+                miss |= e == 0u ? b.u : 0u;
+            }
+            pk.put(e);
+        };
+        WalkA a1 = stageA();
+        WalkA a2 = stageA();
+        WalkB b1 = stageB(a1);
+        // two symbols per trip: the pipeline registers rotate by renaming instead of by moves (an odd
+        // count runs one extra step on the sentinel, a no-op for every lane)
+        for (uint32_t i = 0; i < maxcnt; i += 2) {
+            WalkA a3 = stageA();
+            WalkB b2 = stageB(a2);
+            stageC(b1);
+            WalkA a4 = stageA();
+            WalkB b3 = stageB(a3);
+            stageC(b2);
+            a2 = a4;
+            b1 = b3;
         }
-        // (15,0) at every 16th zero before a later non-zero (a lane that has run out of non-zeros has e == 0)
-        if (b.zr >= 16u && e != 0u) {
-            const uint32_t z = lut2[kLut2Zrl];
-            for (uint32_t i = 0; i < (b.zr >> 4); ++i) pk.put(z);
-        }
-        pk.put(e);
-    };
-
-    WalkA a1 = stageA();
-    WalkA a2 = stageA();
-    WalkB b1 = stageB(a1);
-#if MI355_WALK_UNROLL2
-    // two symbols per trip: the pipeline registers rotate by renaming instead of by moves (an odd
-    // count runs one extra step on the sentinel, a no-op for every lane)
-    for (uint32_t i = 0; i < maxcnt; i += 2) {
-        WalkA a3 = stageA();
-        WalkB b2 = stageB(a2);
-        stageC(b1);
-        WalkA a4 = stageA();
-        WalkB b3 = stageB(a3);
-        stageC(b2);
-        a2 = a4;
-        b1 = b3;
+        if (general || !__any(miss != 0u)) break;
+        general = true;  // walk this pass again, the careful way
+        pk.reset();
     }
-#else
-    for (uint32_t i = 0; i < maxcnt; ++i) {
-        WalkA a3 = stageA();
-        WalkB b2 = stageB(a2);
-        stageC(b1);
-        a2 = a3;
-        b1 = b2;
-    }
-#endif
     // the reference appends EOB ALWAYS (quirk Q8); a standard encoder omits it after coefficient 63
     if (!(STD && (mask >> 63))) pk.put(lut2[kLut2Eob]);
     pk.finish();

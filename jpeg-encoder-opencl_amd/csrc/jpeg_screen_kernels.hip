@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(256, 2)
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wave_t0)::"memory");  // 100 MHz wall clock
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
+    bool walk_general[2] = {false, false};  // per channel type: the last pass had a symbol-table miss (walk_nonzeros)
     for (uint32_t p = pstart; p < pairs_total; p += pstep) {
         STAMP(7);
         uint32_t frame, tile, chan;
@@ -317,8 +318,8 @@ __global__ void __launch_bounds__(256, 2)
                                 &s_mhi[ul], lane);
             }
         }
-        const i16a* row16 = tb16 + row_unit_off(lane);
-        const uint64_t mask = ((uint64_t)s_mhi[lane] << 32 | s_mlo[lane]) & ~1ull;
+        i16a* const row16 = tb16 + row_unit_off(lane);
+        uint64_t mask = ((uint64_t)s_mhi[lane] << 32 | s_mlo[lane]) & ~1ull;
         const int dc = (int)row16[0];
 
         if constexpr (PROBE) {
@@ -329,8 +330,9 @@ __global__ void __launch_bounds__(256, 2)
         }
 
         Packer32<StoreLds> pkr(StoreLds{&s_slot[lane], kSlotRows, kSlotRows * 64u});
+        mask = mark_zero_runs(row16, mask);  // ZRL positions become virtual non-zeros (after the probe dump above)
         const uint32_t maxcnt = wave_max((uint32_t)__popcll(mask));
-        bool ok = walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pkr, maxcnt);
+        bool ok = walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pkr, maxcnt, walk_general[ct]);
         const uint32_t aclen = pkr.bits();
         uint32_t nw = pkr.words();
         STAMP(2);
@@ -372,7 +374,8 @@ __global__ void __launch_bounds__(256, 2)
             if (__any(oversize && nw)) {  // rare: string longer than the LDS slot: walk again, straight to memory
                 if (oversize && nw) {
                     Packer32<StoreGlobal> pg(StoreGlobal{sp.arena + off});
-                    (void)walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pg, maxcnt);
+                    bool gen = true;
+                    (void)walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pg, maxcnt, gen);
                 }
             }
         }
