@@ -449,6 +449,73 @@ __device__ __forceinline__ uint64_t mark_zero_runs(i16a* row, uint64_t mask) {
 // miss on a real value (|v| > 31, or a table with holes) is only recorded; if any lane had one, the wave walks the
 // pass again with the general loop, and `general` (wave-uniform, kept by the caller per channel type) makes it start
 // there next time -- noise at q = 90 lives in the general loop, q = 50 never sees it.
+// One pass over the walk mask.  GENERAL = false: the branch-free loop (table misses on real values are recorded in
+// `miss`); GENERAL = true: misses assemble their symbol from the (run, size) table behind an exec-masked branch.  Two
+// instantiations on purpose: left to itself the compiler keeps ONE loop and guards the general part with exec-mask
+// juggling and a branch per symbol -- the very cost this structure removes.
+template <bool GENERAL, typename Store>
+__device__ __forceinline__ void walk_loop(const u16a* rowu, uint64_t mask, const uint32_t* __restrict__ lut2,
+                                          const uint32_t* __restrict__ act, uint32_t zrl, Packer32<Store>& pk,
+                                          const uint32_t maxcnt, uint32_t& miss, bool& bad) {
+    uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
+    uint32_t prev = 0;
+    auto stageA = [&]() -> WalkA {
+        WalkA a;
+        const uint32_t plo = (uint32_t)(__ffs((int)mlo) - 1);  // 0xFFFFFFFF when mlo == 0
+        uint32_t phi = (uint32_t)(__ffs((int)mhi) - 1);        // 0xFFFFFFFF when mhi == 0
+        phi = (phi < 32u ? phi : 32u) + 32u;                   // ... -> 64 = the sentinel slot
+        a.pos = plo < phi ? plo : phi;
+        // clear the lowest set bit of the 64-bit mask
+        const uint32_t nlo = mlo & (mlo - 1u);
+        const uint32_t nhi = mlo ? mhi : (mhi & (mhi - 1u));
+        mlo = nlo;
+        mhi = nhi;
+        a.u = rowu[a.pos * 64u];
+        return a;
+    };
+    auto stageB = [&](const WalkA& a) -> WalkB {
+        WalkB b;
+        const uint32_t run = a.pos - prev - 1u;  // < 16 for every real symbol and every marker
+        prev = a.pos;
+        b.u = a.u;
+        b.r = run & 15u;
+        // table row = clamp(v, -32, 32) + 32 without sign extension: (u + 32) mod 2^16 is v + 32 for v in [-32, 32] and
+        // something above 64 for every other value, which the minimum sends to row 64 (= +32: an all-zero row)
+        const uint16_t t = (uint16_t)(a.u + 32u);
+        const uint32_t trow = t < 64 ? t : 64;
+        const uint32_t* const lr = lut2 + b.r;
+        b.e_fast = lr[trow * 16u];
+        return b;
+    };
+    auto stageC = [&](const WalkB& b) {
+        uint32_t e = b.u == kZrlMarker ? zrl : b.e_fast;
+        if constexpr (GENERAL) {
+            if (e == 0u && b.u != 0u) {  // no whole-symbol entry: a large value (or a table with holes)
+                e = symbol_slow((int)(int16_t)b.u, b.r, act);
+                bad = bad || e == 0u;
+            }
+        } else {
+            miss |= e == 0u ? b.u : 0u;
+        }
+        pk.put(e);
+    };
+    WalkA a1 = stageA();
+    WalkA a2 = stageA();
+    WalkB b1 = stageB(a1);
+    // two symbols per trip: the pipeline registers rotate by renaming instead of by moves (an odd
+    // count runs one extra step on the sentinel, a no-op for every lane)
+    for (uint32_t i = 0; i < maxcnt; i += 2) {
+        WalkA a3 = stageA();
+        WalkB b2 = stageB(a2);
+        stageC(b1);
+        WalkA a4 = stageA();
+        WalkB b3 = stageB(a3);
+        stageC(b2);
+        a2 = a4;
+        b1 = b3;
+    }
+}
+
 template <bool STD, typename Store>
 __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, const uint32_t* __restrict__ lut2,
                                               const uint32_t* __restrict__ act, Packer32<Store>& pk,
@@ -456,68 +523,15 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
     const u16a* const rowu = reinterpret_cast<const u16a*>(row);
     const uint32_t zrl = lut2[kLut2Zrl];
     bool bad = false;  // a non-zero coefficient without a code (quirk Q13)
-    for (;;) {
-        uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
-        uint32_t prev = 0, miss = 0;
-        auto stageA = [&]() -> WalkA {
-            WalkA a;
-            const uint32_t plo = (uint32_t)(__ffs((int)mlo) - 1);  // 0xFFFFFFFF when mlo == 0
-            uint32_t phi = (uint32_t)(__ffs((int)mhi) - 1);        // 0xFFFFFFFF when mhi == 0
-            phi = (phi < 32u ? phi : 32u) + 32u;                   // ... -> 64 = the sentinel slot
-            a.pos = plo < phi ? plo : phi;
-            // clear the lowest set bit of the 64-bit mask
-            const uint32_t nlo = mlo & (mlo - 1u);
-            const uint32_t nhi = mlo ? mhi : (mhi & (mhi - 1u));
-            mlo = nlo;
-            mhi = nhi;
-            a.u = rowu[a.pos * 64u];
-            return a;
-        };
-        auto stageB = [&](const WalkA& a) -> WalkB {
-            WalkB b;
-            const uint32_t run = a.pos - prev - 1u;  // < 16 for every real symbol and every marker
-            prev = a.pos;
-            b.u = a.u;
-            b.r = run & 15u;
-            // table row = clamp(v, -32, 32) + 32 without sign extension: (u + 32) mod 2^16 is v + 32 for v in [-32, 32] and
-            // something above 64 for every other value, which the minimum sends to row 64 (= +32: an all-zero row)
-            const uint16_t t = (uint16_t)(a.u + 32u);
-            const uint32_t trow = t < 64 ? t : 64;
-            const uint32_t* const lr = lut2 + b.r;
-            b.e_fast = lr[trow * 16u];
-            return b;
-        };
-        auto stageC = [&](const WalkB& b) {
-            uint32_t e = b.u == kZrlMarker ? zrl : b.e_fast;
-            if (general) {
-                if (e == 0u && b.u != 0u) {  // no whole-symbol entry: a large value (or a table with holes)
-                    e = symbol_slow((int)(int16_t)b.u, b.r, act);
-                    bad = bad || e == 0u;
-                }
-            } else {
-                miss |= e == 0u ? b.u : 0u;
-            }
-            pk.put(e);
-        };
-        WalkA a1 = stageA();
-        WalkA a2 = stageA();
-        WalkB b1 = stageB(a1);
-        // two symbols per trip: the pipeline registers rotate by renaming instead of by moves (an odd
-        // count runs one extra step on the sentinel, a no-op for every lane)
-        for (uint32_t i = 0; i < maxcnt; i += 2) {
-            WalkA a3 = stageA();
-            WalkB b2 = stageB(a2);
-            stageC(b1);
-            WalkA a4 = stageA();
-            WalkB b3 = stageB(a3);
-            stageC(b2);
-            a2 = a4;
-            b1 = b3;
+    uint32_t miss = 0;
+    if (!general) {
+        walk_loop<false>(rowu, mask, lut2, act, zrl, pk, maxcnt, miss, bad);
+        if (__any(miss != 0u)) {  // walk this pass again, the careful way; and start there next time
+            general = true;
+            pk.reset();
         }
-        if (general || !__any(miss != 0u)) break;
-        general = true;  // walk this pass again, the careful way
-        pk.reset();
     }
+    if (general) walk_loop<true>(rowu, mask, lut2, act, zrl, pk, maxcnt, miss, bad);
     // the reference appends EOB ALWAYS (quirk Q8); a standard encoder omits it after coefficient 63
     if (!(STD && (mask >> 63))) pk.put(lut2[kLut2Eob]);
     pk.finish();
