@@ -121,7 +121,7 @@ __device__ __forceinline__ void load_raw_rowpair(const uint8_t* __restrict__ f, 
 // and 128e6 are), so floor(x / 1e6) == floor((x / 32) / 31250) with constants that fit 16 bits:
 // 168736/32 = 5273, 331264/32 = 10352, 500000/32 = 15625, 418688/32 = 13084, 81312/32 = 2541.
 // Same results as csc_int for all 2^24 inputs (the exhaustive colour conversion tests run this one).
-template <bool STD>
+template <bool STD, bool NOTIE = false>
 __device__ __forceinline__ uint32_t csc_packed(int chan, uint32_t rg, uint32_t b) {
     typedef short v2s __attribute__((ext_vector_type(2)));
     const v2s RG = __builtin_bit_cast(v2s, rg);
@@ -129,7 +129,8 @@ __device__ __forceinline__ uint32_t csc_packed(int chan, uint32_t rg, uint32_t b
         const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, v2s{299, 587}, (int)(114u * b), false);
         if constexpr (STD) return div1000(s + 500u);  // s <= 255000
         uint32_t y = div1000(s);
-        if (s == __umul24(y, 1000u)) y = csc1(rg & 0xffffu, rg >> 16, b, 0.299, 0.587, 0.114, 0.0);
+        if constexpr (!NOTIE)
+            if (s == __umul24(y, 1000u)) y = csc1(rg & 0xffffu, rg >> 16, b, 0.299, 0.587, 0.114, 0.0);
         return y;
     } else {
         const int kb = chan == 1 ? 15625 : -2541;
@@ -145,21 +146,48 @@ __device__ __forceinline__ uint32_t csc_packed(int chan, uint32_t rg, uint32_t b
 
 // 16 samples of channel CHAN from the raw row pair, packed 4 per dword in sample order
 // (y*8+x), as unsigned bytes; chroma averaging over the 2x2 quads of the row pair.
-template <int CHAN, bool STD>
+// Strict luma: the integer quotient is the reference's value unless the decimal value is an integer (remainder 0, one
+// pixel in a thousand), where the fp64 sum has to be evaluated.  Testing every pixel with an exec-masked branch cost
+// 7 % of the kernel (the branch machinery, not the rare fp64 code): so four pixels are converted branch-free with their
+// remainders (one v_mad_i32_i24 each), and ONE wave-uniform test per four pixels (taken 23 % of the time) guards the
+// per-pixel fix-ups.
+template <int CHAN, bool STD, bool NOTIE = false>
 __device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool avg, uint32_t (&pk)[4]) {
     uint32_t val[2][8];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            // pixel x = bytes 3x, 3x+1, 3x+2 of the row: R and G through a byte permute of the two
-            // dwords around them (selector 0..3 = low dword, 4..7 = high dword, 0x0c = zero)
-            constexpr uint32_t kZ = 0x0cu;
-            const int o = 3 * x, i = o >> 2, k = o & 3;
-            const uint32_t lo = w[r * 6 + i], hi = w[r * 6 + (i < 5 ? i + 1 : i)];
-            const uint32_t rg = __builtin_amdgcn_perm(hi, lo, (uint32_t)k | (kZ << 8) | ((uint32_t)(k + 1) << 16) | (kZ << 24));
-            const uint32_t b = (w[r * 6 + ((o + 2) >> 2)] >> (8 * ((o + 2) & 3))) & 255u;
-            val[r][x] = csc_packed<STD>(CHAN, rg, b);
+        for (int h = 0; h < 2; ++h) {
+            uint32_t rgs[4], bs[4], rem[4];
+#pragma unroll
+            for (int xx = 0; xx < 4; ++xx) {
+                const int x = 4 * h + xx;
+                // pixel x = bytes 3x, 3x+1, 3x+2 of the row: R and G through a byte permute of the two
+                // dwords around them (selector 0..3 = low dword, 4..7 = high dword, 0x0c = zero)
+                constexpr uint32_t kZ = 0x0cu;
+                const int o = 3 * x, i = o >> 2, k = o & 3;
+                const uint32_t lo = w[r * 6 + i], hi = w[r * 6 + (i < 5 ? i + 1 : i)];
+                const uint32_t rg = __builtin_amdgcn_perm(hi, lo, (uint32_t)k | (kZ << 8) | ((uint32_t)(k + 1) << 16) | (kZ << 24));
+                const uint32_t b = (w[r * 6 + ((o + 2) >> 2)] >> (8 * ((o + 2) & 3))) & 255u;
+                if constexpr (CHAN == 0 && !STD) {
+                    typedef short v2s __attribute__((ext_vector_type(2)));
+                    const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, rg), v2s{299, 587}, (int)(114u * b), false);
+                    const uint32_t y = div1000(s);
+                    val[r][x] = y;
+                    rgs[xx] = rg, bs[xx] = b;
+                    rem[xx] = s - __umul24(y, 1000u);
+                } else {
+                    val[r][x] = csc_packed<STD, NOTIE>(CHAN, rg, b);
+                }
+            }
+            if constexpr (CHAN == 0 && !STD && !NOTIE) {
+                const uint32_t m01 = rem[0] < rem[1] ? rem[0] : rem[1], m23 = rem[2] < rem[3] ? rem[2] : rem[3];
+                if (__any((m01 < m23 ? m01 : m23) == 0u)) {
+#pragma unroll
+                    for (int xx = 0; xx < 4; ++xx)
+                        if (rem[xx] == 0u) val[r][4 * h + xx] = csc1(rgs[xx] & 0xffffu, rgs[xx] >> 16, bs[xx], 0.299, 0.587, 0.114, 0.0);
+                }
+            }
         }
     if (avg) {
 #pragma unroll

@@ -230,7 +230,11 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
                 for (int i = 0; i < 12; ++i) cur[i] = raw[i];
                 if (j < 3) load_raw_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, raw);
+#ifdef MI355_DIAG_NOTIE  // timing experiment only (wrong in 1 luma sample of 1000): luma without the tie check
+                if (comp == 0) convert_rowpair<0, STD, true>(cur, false, pk);
+#else
                 if (comp == 0) convert_rowpair<0, STD>(cur, false, pk);
+#endif
                 else if (comp == 1) convert_rowpair<1, STD>(cur, avg, pk);
                 else convert_rowpair<2, STD>(cur, avg, pk);
             } else {
