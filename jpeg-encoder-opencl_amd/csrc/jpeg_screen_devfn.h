@@ -10,6 +10,9 @@ namespace mi355 {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+// "does any active lane say yes": the ballot's SGPR pair compared on the scalar unit (HIP's __any goes through a
+// v_cndmask + v_cmp pair first)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // the zig-zag rows are written as packed uint32 pairs and read back as int16: tell TBAA
 typedef int16_t __attribute__((may_alias)) i16a;
 
@@ -182,7 +185,7 @@ __device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool av
             }
             if constexpr (CHAN == 0 && !STD && !NOTIE) {
                 const uint32_t m01 = rem[0] < rem[1] ? rem[0] : rem[1], m23 = rem[2] < rem[3] ? rem[2] : rem[3];
-                if (__any((m01 < m23 ? m01 : m23) == 0u)) {
+                if (wave_any((m01 < m23 ? m01 : m23) == 0u)) {
 #pragma unroll
                     for (int xx = 0; xx < 4; ++xx)
                         if (rem[xx] == 0u) val[r][4 * h + xx] = csc1(rgs[xx] & 0xffffu, rgs[xx] >> 16, bs[xx], 0.299, 0.587, 0.114, 0.0);
@@ -453,7 +456,7 @@ __device__ __forceinline__ uint64_t mark_zero_runs(i16a* row, uint64_t mask) {
         y |= y << 4;
         y |= y << 8;
         const uint64_t f = x & ~(y << 1) & ~1ull;  // non-zeros (real or virtual) with 16+ zeros in front
-        if (!__any(f != 0)) break;
+        if (!wave_any(f != 0)) break;
         if (f != 0) {
             const uint32_t q = (uint32_t)__builtin_ctzll(f);
             const uint32_t p = 63u - (uint32_t)__builtin_clzll(x & ((1ull << q) - 1ull));  // the non-zero before the run
@@ -554,7 +557,7 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
     uint32_t miss = 0;
     if (!general) {
         walk_loop<false>(rowu, mask, lut2, act, zrl, pk, maxcnt, miss, bad);
-        if (__any(miss != 0u)) {  // walk this pass again, the careful way; and start there next time
+        if (wave_any(miss != 0u)) {  // walk this pass again, the careful way; and start there next time
             general = true;
             pk.reset();
         }
@@ -635,7 +638,7 @@ __device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], con
         a1[r] = !(__builtin_fmaf(__builtin_fabsf(zz[r]), 0x1p-21f, __builtin_fabsf(dd[r])) < qf[4 + r]);
         if (mt == 0 && r == 0 && gq == 0) a1[r] = false;  // coefficient 0: overwritten by the caller
     }
-    if (__any(a1[0] || a1[1] || a1[2] || a1[3])) {
+    if (wave_any(a1[0] || a1[1] || a1[2] || a1[3])) {
         if (lane == 0) atomicAdd(&sp.stats[0], 1ull);
         const uint4 t1 = sp.afrag[(mt * kScreenLimbs + 1) * 64 + lane], t0 = sp.afrag[(mt * kScreenLimbs) * 64 + lane];
         const v4i acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w}, B,
