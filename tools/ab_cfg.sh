@@ -1,0 +1,8 @@
+#!/bin/bash
+# GPU box helper: tools/config_bench.py cases with two builds of the library (A = libmi355jpeg_prev.so, B = current)
+set -e
+P=$GRAFT_REPO_ROOT/jpeg-encoder-opencl_amd
+for r in 1 2; do
+  echo "A$r"; MI355_JPEG_LIB=$P/libmi355jpeg_prev.so python tools/config_bench.py "$@" 2>/dev/null | python -c "import sys,json; [print('  ', j['case'], j['Gpixel_per_s']) for j in map(json.loads, sys.stdin)]"
+  echo "B$r"; python tools/config_bench.py "$@" 2>/dev/null | python -c "import sys,json; [print('  ', j['case'], j['Gpixel_per_s']) for j in map(json.loads, sys.stdin)]"
+done
