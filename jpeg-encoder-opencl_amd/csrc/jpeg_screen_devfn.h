@@ -429,7 +429,8 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {  // uniform result
 
 struct WalkA {  // stage A result: position of a symbol + its value read in flight
     uint32_t pos;
-    uint32_t u;  // the coefficient as stored: 16 bits, zero-extended
+    uint32_t run;  // zeros between the previous symbol and this one
+    uint32_t u;    // the coefficient as stored: 16 bits, zero-extended
 };
 struct WalkB {  // stage B result: symbol entry read in flight
     uint32_t e_fast;
@@ -488,28 +489,29 @@ template <bool GENERAL, typename Store>
 __device__ __forceinline__ void walk_loop(const u16a* rowu, uint64_t mask, const uint32_t* __restrict__ lut2,
                                           const uint32_t* __restrict__ act, uint32_t zrl, Packer32<Store>& pk,
                                           const uint32_t maxcnt, uint32_t& miss, bool& bad) {
-    uint32_t mlo = (uint32_t)mask, mhi = (uint32_t)(mask >> 32);
-    uint32_t prev = 0;
+    // The mask is kept SHIFTED: bit 0 of m = the position after the last symbol taken.  After mark_zero_runs the next
+    // symbol is never more than 16 positions away, so it is always found in the low word (one v_ffbl_b32, no 64-bit
+    // search, no clearing of the bit found: the shift drops it).  A lane that has run out (m == 0: ffbl = 0xFFFFFFFF)
+    // is sent to the sentinel position 64 and stays there.
+    uint64_t m = mask >> 1;
+    uint32_t prev = 0;  // position of the last symbol handed out by stage A
     auto stageA = [&]() -> WalkA {
         WalkA a;
-        const uint32_t plo = (uint32_t)(__ffs((int)mlo) - 1);  // 0xFFFFFFFF when mlo == 0
-        uint32_t phi = (uint32_t)(__ffs((int)mhi) - 1);        // 0xFFFFFFFF when mhi == 0
-        phi = (phi < 32u ? phi : 32u) + 32u;                   // ... -> 64 = the sentinel slot
-        a.pos = plo < phi ? plo : phi;
-        // clear the lowest set bit of the 64-bit mask
-        const uint32_t nlo = mlo & (mlo - 1u);
-        const uint32_t nhi = mlo ? mhi : (mhi & (mhi - 1u));
-        mlo = nlo;
-        mhi = nhi;
+        uint32_t t;  // run in front of the symbol; 127 = none left (v_ffbl_b32 of 0 is 0xFFFFFFFF; __ffs costs four more)
+        asm("v_ffbl_b32 %0, %1" : "=v"(t) : "v"((uint32_t)m));
+        t &= 127u;
+        const uint32_t nx = prev + t + 1u;
+        a.pos = nx < 64u ? nx : 64u;
+        a.run = t;
+        m >>= (t + 1u) & 63u;
+        prev = a.pos;
         a.u = rowu[a.pos * 64u];
         return a;
     };
     auto stageB = [&](const WalkA& a) -> WalkB {
         WalkB b;
-        const uint32_t run = a.pos - prev - 1u;  // < 16 for every real symbol and every marker
-        prev = a.pos;
         b.u = a.u;
-        b.r = run & 15u;
+        b.r = a.run & 15u;  // < 16 already for every real symbol and every marker
         // table row = clamp(v, -32, 32) + 32 without sign extension: (u + 32) mod 2^16 is v + 32 for v in [-32, 32] and
         // something above 64 for every other value, which the minimum sends to row 64 (= +32: an all-zero row)
         const uint16_t t = (uint16_t)(a.u + 32u);
