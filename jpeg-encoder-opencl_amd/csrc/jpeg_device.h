@@ -36,7 +36,7 @@ struct ScreenParams {
     const double* qd;       // [2][64] quantiser divisors as doubles, natural order
     const uint32_t* qnat_zz; // [2][64] quantiser divisors as integers, ZIG-ZAG order (standard mode's exact decision)
     const uint32_t* lut;    // [4][256] Huffman LUTs (code << 5 | len)
-    const uint32_t* lut2;   // [2 channel types][16 runs][64 values+32] whole AC symbols, left-aligned | length
+    const uint32_t* lut2;   // [2 channel types][66 rows: value + 32][16 columns: run] whole AC symbols, left-aligned | length
     uint2* meta;            // [frame][tile][chan][64] {arena word offset, aclen << 16 | (uint16)dc}
     uint32_t* arena;        // AC bit strings, one word-aligned blob per unit
     uint32_t arena_words;   // = grid * region_words + overflow pool

@@ -28,7 +28,7 @@ constexpr uint32_t kSlotWordsFull = 54;  // worst case 63*(17+10)+4 = 1705 bits
 // coefficient at MY next non-zero position" -- 64 data-dependent positions per wave instruction --
 // and with this layout the 32 lanes of each LDS lane group always hit 32 different banks (the
 // stride-33 unit-major rows of round 1 collided at random: 38 % of the LDS-active cycles were bank
-// conflicts).  Position 64 is a zero sentinel row (read by lanes that have run out of non-zeros).
+// conflicts).  Position 64 is a sentinel row holding kRowSentinel (read by lanes that have run out of symbols).
 constexpr uint32_t kRowWords = 65 * 32;  // dwords per wave
 __device__ __forceinline__ uint32_t row_unit_off(uint32_t u) { return ((u & 31u) << 1) | (u >> 5); }
 
@@ -333,17 +333,28 @@ struct WaveArena {
 #define MI355_SLOT_ROWS 24
 #endif
 constexpr uint32_t kSlotRows = MI355_SLOT_ROWS;  // words per unit in the LDS slot; larger strings re-walk into global memory
-// Symbol table layout [value + 32][run] (index (v + 32) * 16 + r), values clamped to [-32, 32]: 65 rows of 16
-// entries.  The value-0 row (entries 512..527) is all zero (no-op for exhausted lanes, whatever their run); the
-// rows of -32 and +32 are all zero too ("no whole-symbol entry": larger values are clamped onto them and take the
-// slow path); a 66th row carries ZRL (run 15) and EOB (run 0).
-// Run-minor on purpose: an LDS bank is (index mod 32) = 16 * (v & 1) + r, so lanes that code the same value
-// (on noise 70 % of the symbols are +-1) after different runs read different banks.  The run-major
-// layout of round 1 put every lane with the same value on ONE bank at up to 16 different addresses:
-// that was most of the kernel's LDS bank conflicts.
-constexpr uint32_t kLut2Rows = 66, kLut2Words = kLut2Rows * 16;  // per channel type
-constexpr uint32_t kLut2Zrl = 65 * 16 + 15;
-constexpr uint32_t kLut2Eob = 65 * 16;
+// Symbol table layout [value + 32][run] (index (v + 32) * 16 + run), values clamped to [-32, 32]: 65 rows of 16
+// entries, and a 66th row.  The rows of -32 and +32 are kLut2Miss in every column ("no whole-symbol entry": larger
+// values are clamped onto them and take the slow path).  The value-0 row holds ZRL in column 15 and nothing else: the
+// walk visits a zero coefficient only at the positions mark_zero_runs adds to its mask -- always with run 15 -- so ZRL
+// needs no marker value, no compare and no select.  A lane that has run out of symbols reads the sentinel position 64
+// of its row buffer, which holds kRowSentinel = 29, with "run" kRunNone = 64: index (29 + 32) * 16 + 64 = entry 0 of
+// the 66th row, which is zero -- a no-op put.  EOB is entry 1 of the 66th row.
+// Run-minor on purpose: an LDS bank is (16 (v & 1) + run) mod 32, so lanes that code the same value (on noise 70 %
+// of the symbols are +-1) after different runs read different banks.  The run-major layout of round 1 put every
+// lane with the same value on ONE bank at up to 16 different addresses: that was most of the kernel's LDS bank
+// conflicts.  (A 17-column layout with a zero column for the exhausted lanes was 528 bytes larger: k_merge's
+// workgroup no longer fitted next to two of the block-encode kernel's on a CU, and batched calls lost 20 %.)
+constexpr uint32_t kLut2Cols = 16, kLut2Rows = 66, kLut2Words = kLut2Rows * kLut2Cols;  // per channel type
+constexpr uint32_t kLut2Zrl = 32 * kLut2Cols + 15;
+constexpr uint32_t kLut2Eob = 65 * kLut2Cols + 1;
+constexpr uint32_t kRunNone = 64;      // "run" of a lane without symbols left (v_ffbl_b32 of 0, clamped)
+constexpr uint32_t kRowSentinel = 29;  // value at position 64 of every unit's row
+static_assert((kRowSentinel + 32) * kLut2Cols + kRunNone == 65 * kLut2Cols, "exhausted lanes must land on the zero entry of the 66th row");
+// "No whole-symbol entry" (a value outside [-31, 31], or a hole in the caller's Huffman table): length field 31, which
+// no symbol has (<= 27).  The branch-free walk puts it like any entry -- the pass is walked again anyway -- and
+// notices through the running maximum of the length fields: one instruction per symbol.
+constexpr uint32_t kLut2Miss = 31u;
 
 // Left-aligned 32-bit bit packer.  e = symbol bits left-aligned | length (<= 27) in bits 4..0.
 // Every put stores the word being filled (a later put to the same word overwrites it).
@@ -441,14 +452,12 @@ typedef uint16_t __attribute__((may_alias)) u16a;
 
 // ZRLs without a branch in the walk.  The reference emits (15,0) at every 16th zero of a run that ends in a non-zero
 // (RLEBlockAC, utils.cpp:586-596).  Those positions -- prev + 16, prev + 32, ... below the next non-zero -- are made
-// "virtual non-zeros" before the walk: their bit is set in the walk mask and a marker value that no coefficient can
-// have (AC categories end at 10 bits) is written into the (otherwise dead) row buffer, so the walk visits them like
-// any symbol, selects the ZRL code for the marker, and every run it ever sees is below 16.  Finding them is a short
-// wave-uniform loop of 64-bit bit tricks: one round per ZRL of the unit that has the most (none in 99 % of the luma
-// units of noise, one or two in a third of the chroma units); one cheap round when there is nothing to do.
-// All lanes must be active.  Returns the walk mask (bit 0 clear).
-constexpr uint32_t kZrlMarker = 0x7FFFu;
-__device__ __forceinline__ uint64_t mark_zero_runs(i16a* row, uint64_t mask) {
+// "virtual non-zeros" before the walk: their bit is set in the walk mask, so the walk visits them like any symbol --
+// a ZERO coefficient after a run of 15, which is exactly where the symbol table keeps ZRL -- and every run it ever
+// sees is below 16.  Finding them is a short wave-uniform loop of 64-bit bit tricks: one round per ZRL of the unit
+// that has the most (none in 99 % of the luma units of noise, one or two in a third of the chroma units); one cheap
+// round when there is nothing to do.  All lanes must be active.  Returns the walk mask (bit 0 clear).
+__device__ __forceinline__ uint64_t mark_zero_runs(uint64_t mask) {
     uint64_t x = mask | 1ull;  // position 0 counts as the start of the first run
     for (;;) {
         uint64_t y = x;  // bit q of y: x has a bit in [q - 15, q]
@@ -461,45 +470,43 @@ __device__ __forceinline__ uint64_t mark_zero_runs(i16a* row, uint64_t mask) {
         if (f != 0) {
             const uint32_t q = (uint32_t)__builtin_ctzll(f);
             const uint32_t p = 63u - (uint32_t)__builtin_clzll(x & ((1ull << q) - 1ull));  // the non-zero before the run
-            const uint32_t ins = p + 16u;                                                   // < q
-            x |= 1ull << ins;
-            row[ins * 64u] = (int16_t)kZrlMarker;
+            x |= 1ull << (p + 16u);                                                         // < q
         }
     }
     return x & ~1ull;
 }
 
 // row: this lane's unit in the [position][unit] row buffer (row[pos * 64] = coefficient at zig-zag
-// position pos; position 64 = 0, the sentinel); mask: the walk mask from mark_zero_runs (non-zero positions 1..63 plus
-// the ZRL markers).  A lane that has run out of non-zeros keeps reading the sentinel: value 0
-// selects the all-zero row of the symbol table, i.e. a no-op put -- no validity bookkeeping.
-// maxcnt: wave-uniform upper bound of the lanes' mask populations (wave_max of popcount(mask),
+// position pos; position 64 = kRowSentinel); mask: the walk mask from mark_zero_runs (non-zero positions 1..63 plus
+// the ZRL positions).  maxcnt: wave-uniform upper bound of the lanes' mask populations (wave_max of popcount(mask),
 // formed by the caller with all lanes active: DPP reductions need the full wave).
-// Per symbol: next set bit of the 64-bit mask, one 16-bit LDS read of the value, one table read with the clamped
-// value (no validity select), the marker select, one put -- and NO branch: in-kernel experiments showed the walk bound
-// by its two exec-masked branches per symbol (rare-path tests), not by its VALU count or its LDS round trips.  A table
-// miss on a real value (|v| > 31, or a table with holes) is only recorded; if any lane had one, the wave walks the
-// pass again with the general loop, and `general` (wave-uniform, kept by the caller per channel type) makes it start
-// there next time -- noise at q = 90 lives in the general loop, q = 50 never sees it.
+// Per symbol: one v_ffbl_b32 on the shifted mask, one 16-bit LDS read of the value, one table read at
+// [clamped value][run], one put -- and NO branch and no select: in-kernel experiments showed the walk bound by its
+// exec-masked branches per symbol (rare-path tests), then by its instruction count, not by its LDS round trips.  A
+// table miss on a real value (|v| > 31, or a table with holes) is only recorded; if any lane had one, the wave walks
+// the pass again with the general loop, and `general` (wave-uniform, kept by the caller per channel type) makes it
+// start there next time -- noise at q = 90 lives in the general loop, q = 50 never sees it.
 // One pass over the walk mask.  GENERAL = false: the branch-free loop (table misses on real values are recorded in
 // `miss`); GENERAL = true: misses assemble their symbol from the (run, size) table behind an exec-masked branch.  Two
 // instantiations on purpose: left to itself the compiler keeps ONE loop and guards the general part with exec-mask
 // juggling and a branch per symbol -- the very cost this structure removes.
+// lut2 (and row) MUST live in LDS: the table read forms its LDS byte address by hand.
 template <bool GENERAL, typename Store>
 __device__ __forceinline__ void walk_loop(const u16a* rowu, uint64_t mask, const uint32_t* __restrict__ lut2,
-                                          const uint32_t* __restrict__ act, uint32_t zrl, Packer32<Store>& pk,
+                                          const uint32_t* __restrict__ act, Packer32<Store>& pk,
                                           const uint32_t maxcnt, uint32_t& miss, bool& bad) {
     // The mask is kept SHIFTED: bit 0 of m = the position after the last symbol taken.  After mark_zero_runs the next
     // symbol is never more than 16 positions away, so it is always found in the low word (one v_ffbl_b32, no 64-bit
     // search, no clearing of the bit found: the shift drops it).  A lane that has run out (m == 0: ffbl = 0xFFFFFFFF)
-    // is sent to the sentinel position 64 and stays there.
+    // gets "run" kRunNone = 64, which takes it straight to the sentinel position 64, where it stays; the table entry
+    // [kRowSentinel][64] is entry 0 of the 66th row: zero.
     uint64_t m = mask >> 1;
     uint32_t prev = 0;  // position of the last symbol handed out by stage A
     auto stageA = [&]() -> WalkA {
         WalkA a;
-        uint32_t t;  // run in front of the symbol; 127 = none left (v_ffbl_b32 of 0 is 0xFFFFFFFF; __ffs costs four more)
+        uint32_t t;  // v_ffbl_b32 of 0 is 0xFFFFFFFF (__ffs costs four instructions more)
         asm("v_ffbl_b32 %0, %1" : "=v"(t) : "v"((uint32_t)m));
-        t &= 127u;
+        t = t < kRunNone ? t : kRunNone;  // zeros in front of the symbol (< 16); kRunNone = none left
         const uint32_t nx = prev + t + 1u;
         a.pos = nx < 64u ? nx : 64u;
         a.run = t;
@@ -511,24 +518,29 @@ __device__ __forceinline__ void walk_loop(const u16a* rowu, uint64_t mask, const
     auto stageB = [&](const WalkA& a) -> WalkB {
         WalkB b;
         b.u = a.u;
-        b.r = a.run & 15u;  // < 16 already for every real symbol and every marker
+        b.r = a.run;
         // table row = clamp(v, -32, 32) + 32 without sign extension: (u + 32) mod 2^16 is v + 32 for v in [-32, 32] and
         // something above 64 for every other value, which the minimum sends to row 64 (= +32: an all-zero row)
         const uint16_t t = (uint16_t)(a.u + 32u);
         const uint32_t trow = t < 64 ? t : 64;
-        const uint32_t* const lr = lut2 + b.r;
-        b.e_fast = lr[trow * 16u];
+        // LDS byte address by hand -- one shift-add, one 24-bit multiply-add (the compiler prefers three instructions)
+        typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
+        const uint32_t col = (uint32_t)(uintptr_t)(lds_u32)lut2 + (b.r << 2);
+        uint32_t addr;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(trow), "s"(kLut2Cols * 4u), "v"(col));
+        b.e_fast = *(lds_u32)(uintptr_t)addr;
         return b;
     };
     auto stageC = [&](const WalkB& b) {
-        uint32_t e = b.u == kZrlMarker ? zrl : b.e_fast;
+        uint32_t e = b.e_fast;
         if constexpr (GENERAL) {
-            if (e == 0u && b.u != 0u) {  // no whole-symbol entry: a large value (or a table with holes)
+            if ((e & 31u) == kLut2Miss) {  // no whole-symbol entry: a large value (or a table with holes)
                 e = symbol_slow((int)(int16_t)b.u, b.r, act);
                 bad = bad || e == 0u;
             }
         } else {
-            miss |= e == 0u ? b.u : 0u;
+            const uint32_t len = e & 31u;
+            miss = miss > len ? miss : len;
         }
         pk.put(e);
     };
@@ -554,17 +566,16 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
                                               const uint32_t* __restrict__ act, Packer32<Store>& pk,
                                               const uint32_t maxcnt, bool& general) {
     const u16a* const rowu = reinterpret_cast<const u16a*>(row);
-    const uint32_t zrl = lut2[kLut2Zrl];
     bool bad = false;  // a non-zero coefficient without a code (quirk Q13)
     uint32_t miss = 0;
     if (!general) {
-        walk_loop<false>(rowu, mask, lut2, act, zrl, pk, maxcnt, miss, bad);
-        if (wave_any(miss != 0u)) {  // walk this pass again, the careful way; and start there next time
+        walk_loop<false>(rowu, mask, lut2, act, pk, maxcnt, miss, bad);
+        if (wave_any(miss == kLut2Miss)) {  // walk this pass again, the careful way; and start there next time
             general = true;
             pk.reset();
         }
     }
-    if (general) walk_loop<true>(rowu, mask, lut2, act, zrl, pk, maxcnt, miss, bad);
+    if (general) walk_loop<true>(rowu, mask, lut2, act, pk, maxcnt, miss, bad);
     // the reference appends EOB ALWAYS (quirk Q8); a standard encoder omits it after coefficient 63
     if (!(STD && (mask >> 63))) pk.put(lut2[kLut2Eob]);
     pk.finish();

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256, 2)
     for (uint32_t i = tid; i < 2 * kLut2Words; i += 256) (&s_lut2[0][0])[i] = sp.lut2[i];
     (&s_qf[0][0][0])[tid] = sp.qconst_f[tid];
     if (tid < 32) s_dc[tid >> 4][tid & 15] = sp.lut[(tid >> 4) * 256 + (tid & 15)];
-    if (lane < 32) s_tbuf[64 * 32 + lane] = 0;  // sentinel row after zig-zag position 63 (never written again)
+    if (lane < 32) s_tbuf[64 * 32 + lane] = kRowSentinel * 0x00010001u;  // sentinel row after zig-zag position 63 (never written again)
     i16a* const tb16 = reinterpret_cast<i16a*>(s_tbuf);
     // A fragments of the top three digits stay in registers; the two low digits only matter for the
     // (rare) second look and are fetched on demand.
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(256, 2)
         }
 
         Packer32<StoreLds> pkr(StoreLds{&s_slot[lane], kSlotRows, kSlotRows * 64u});
-        mask = mark_zero_runs(row16, mask);  // ZRL positions become virtual non-zeros (after the probe dump above)
+        mask = mark_zero_runs(mask);  // ZRL positions become virtual non-zeros (after the probe dump above)
         const uint32_t maxcnt = wave_max((uint32_t)__popcll(mask));
         bool ok = walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pkr, maxcnt, walk_general[ct]);
         const uint32_t aclen = pkr.bits();

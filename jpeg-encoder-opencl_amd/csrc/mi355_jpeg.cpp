@@ -281,10 +281,10 @@ int upload_tables(mi355_jpeg_ctx* c) {
     HIP_TRY(hipMemcpy(c->d_qconst_f, qf, sizeof qf, hipMemcpyHostToDevice));
     // Whole-symbol tables of the screened pipeline's unit walk: for run r and value v (|v| <= 31)
     // the Huffman code of (r, size(v)) followed by v's value bits, left-aligned in 32 bits, with
-    // the total length in bits 4..0; 0 = the reference has no code.  Layout [v + 32][r] (see
-    // jpeg_screen_devfn.h: LDS banks).  The value-0 row stays 0 (a no-op for lanes that ran out of
-    // non-zeros); ZRL and EOB live in the unused value -32 row.
-    constexpr size_t kL2 = 66 * 16;  // kLut2Words (jpeg_screen_devfn.h)
+    // the total length in bits 4..0; 0 = the reference has no code.  Layout [v + 32][run]; the value-0 row holds ZRL
+    // at run 15 and nothing else; the 66th row = {0 (lanes that ran out of symbols land here), EOB, 0, ...}
+    // (jpeg_screen_devfn.h: kLut2Cols, kLut2Zrl, kLut2Eob).
+    constexpr size_t kL2C = 16, kL2 = 66 * kL2C;  // kLut2Cols, kLut2Words
     std::vector<uint32_t> lut2(2 * 2 * kL2, 0u);
     for (int m = 0; m < 2; ++m)
         for (int ct = 0; ct < 2; ++ct) {
@@ -297,13 +297,17 @@ int upload_tables(mi355_jpeg_ctx* c) {
                     int a = v < 0 ? -v : v, size = 0;
                     while (a) ++size, a >>= 1;
                     int rs = (r << 4) | size;
-                    if (!t.len[rs]) continue;
+                    if (!t.len[rs]) {  // a hole in the table: kLut2Miss, the general loop reports it (quirk Q13)
+                        L[(v + 32) * kL2C + r] = 31u;
+                        continue;
+                    }
                     uint32_t vb = (uint32_t)(v < 0 ? v + (1 << size) - 1 : v);
-                    L[(v + 32) * 16 + r] = entry((t.code[rs] << size) | vb, t.len[rs] + size);
+                    L[(v + 32) * kL2C + r] = entry((t.code[rs] << size) | vb, t.len[rs] + size);
                 }
-            // rows 0 (-32), 32 (0) and 64 (+32) stay zero; ZRL and EOB live in row 65
-            L[65 * 16 + 15] = entry(t.code[0xF0], t.len[0xF0]);
-            L[65 * 16] = entry(t.code[0x00], t.len[0x00]);
+            // rows 0 (-32) and 64 (+32): kLut2Miss in every run column (larger values are clamped onto them)
+            for (int r = 0; r < 16; ++r) L[r] = L[64 * kL2C + r] = 31u;
+            L[32 * kL2C + 15] = entry(t.code[0xF0], t.len[0xF0]);
+            L[65 * kL2C + 1] = entry(t.code[0x00], t.len[0x00]);
         }
     HIP_TRY(hipMemcpy(c->d_lut2, lut2.data(), lut2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     // copies from pageable memory may return before the DMA has landed; encode calls run on
