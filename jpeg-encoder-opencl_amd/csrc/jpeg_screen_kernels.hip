@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(256, 2)
 
             bool amb = false;
             uint32_t nzlo = 0, nzhi = 0;  // this lane's part of the unit's non-zero mask
+            uint32_t qprev[4];            // values of the even row tile, paired with the odd one for the mask
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 uint32_t qb[4];  // low 16 bits = quantised value
@@ -276,10 +277,24 @@ __global__ void __launch_bounds__(256, 2)
                 i16a* row = tb16 + (16 * mt + 4 * gq) * 64 + row_unit_off(16 * j + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) row[r * 64] = (int16_t)qb[r];
-                const uint32_t nib = ((qb[0] & 0xffffu) ? 1u : 0u) | ((qb[1] & 0xffffu) ? 2u : 0u) |
-                                     ((qb[2] & 0xffffu) ? 4u : 0u) | ((qb[3] & 0xffffu) ? 8u : 0u);
-                if (mt < 2) nzlo |= nib << (16 * mt);
-                else nzhi |= nib << (16 * (mt - 2));
+                // Non-zero bits, two values per instruction: the 16-bit values of row tiles mt - 1 and mt side by side
+                // (one v_perm_b32), min(value, 1) on both halves (one v_pk_min_u16) = the flags at bits 0 and 16 --
+                // exactly where positions 16 (mt - 1) + r and 16 mt + r sit in the mask word -- shifted in by r.
+                if (mt & 1) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t pr = __builtin_amdgcn_perm(qb[r], qprev[r], 0x05040100u);  // qprev.lo16 | qb.lo16 << 16
+                        uint32_t f;  // (the compiler turns min(x, 1) into two compares and two selects)
+                        asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(f) : "v"(pr));
+                        w |= f << r;
+                    }
+                    if (mt == 1) nzlo = w;
+                    else nzhi = w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) qprev[r] = qb[r];
+                }
             }
             atomicOr(&s_mlo[16 * j + n], (nzlo << (4 * gq)) & ~1u);
             atomicOr(&s_mhi[16 * j + n], nzhi << (4 * gq));
