@@ -107,8 +107,11 @@ __device__ __forceinline__ void load_raw_rowpair(const uint8_t* __restrict__ f, 
                                                  uint32_t by, uint32_t gq, uint32_t (&w)[12]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const uint2* p =
-            reinterpret_cast<const uint2*>(f + ((size_t)(by * 8 + gq * 2 + r) * g.W + bx * 8) * 3);
+        // 32-bit byte offset from the (wave-uniform) frame base: the loads take the base from SGPRs and the address
+        // costs two 32-bit instructions instead of a chain of quarter-rate v_mad_u64_u32 (fast_rows guarantees
+        // W * H * 3 < 2^32)
+        const uint32_t off = (__umul24(by * 8 + gq * 2 + r, g.W) + bx * 8) * 3u;  // rows and widths are below 2^24
+        const uint2* p = reinterpret_cast<const uint2*>(f + off);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             uint2 v = p[j];
@@ -231,7 +234,8 @@ __device__ __forceinline__ void load_raw_mcu_rows(const uint8_t* __restrict__ f,
                                                   uint32_t my, uint32_t row0, uint32_t (&w)[24]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const uint2* p = reinterpret_cast<const uint2*>(f + ((size_t)(my * 16 + row0 + r) * g.W + mx * 16) * 3);
+        const uint32_t off = (__umul24(my * 16 + row0 + r, g.W) + mx * 16) * 3u;  // see load_raw_rowpair
+        const uint2* p = reinterpret_cast<const uint2*>(f + off);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             uint2 v = p[i];

@@ -353,7 +353,8 @@ int make_geom(uint32_t W, uint32_t H, uint32_t flags, const void* base, Geom* g)
     g->tiles = (g->N + 63) / 64;
     g->flags = flags;
     g->frame_stride = (uint64_t)W * H * 3;
-    g->fast_rows = (W % 8 == 0) && (((uintptr_t)base & 7u) == 0);
+    // the fast row loads use 32-bit byte offsets inside a frame (load_raw_rowpair)
+    g->fast_rows = (W % 8 == 0) && (((uintptr_t)base & 7u) == 0) && ((uint64_t)W * H * 3u < (1ull << 32));
     return MI355_OK;
 }
 
