@@ -196,18 +196,22 @@ __device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool av
             }
         }
     if (avg) {
+        // every 2x2 quad becomes its truncated mean: both rows are m0 m0 m1 m1 | m2 m2 m3 m3 (one byte permute each)
+        uint32_t m[4];
 #pragma unroll
-        for (int x = 0; x < 8; x += 2) {
-            uint32_t m = (val[0][x] + val[0][x + 1] + val[1][x] + val[1][x + 1]) >> 2;
-            val[0][x] = val[0][x + 1] = val[1][x] = val[1][x + 1] = m;
-        }
+        for (int x = 0; x < 4; ++x) m[x] = (val[0][2 * x] + val[0][2 * x + 1] + val[1][2 * x] + val[1][2 * x + 1]) >> 2;
+        pk[0] = __builtin_amdgcn_perm(m[1], m[0], 0x04040000u);
+        pk[1] = __builtin_amdgcn_perm(m[3], m[2], 0x04040000u);
+        pk[2] = pk[0];
+        pk[3] = pk[1];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                pk[r * 2 + h] = val[r][4 * h] | (val[r][4 * h + 1] << 8) | (val[r][4 * h + 2] << 16) |
+                                (val[r][4 * h + 3] << 24);
     }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            pk[r * 2 + h] = val[r][4 * h] | (val[r][4 * h + 1] << 8) | (val[r][4 * h + 2] << 16) |
-                            (val[r][4 * h + 3] << 24);
 }
 
 // Edge / unaligned tiles: one sample at a time with mirroring.
