@@ -384,7 +384,11 @@ __global__ void __launch_bounds__(256, 2)
         if (!fits) {
             if (lane == 0) atomicOr(sp.status, 2u);  // MI355_E_CAPACITY
         } else {
+#ifdef MI355_DIAG_NOARENA  // timing experiment only (wrong output): no AC strings written
+            const uint32_t ncopy = 0u;
+#else
             const uint32_t ncopy = oversize ? 0u : nw;
+#endif
 #pragma unroll
             for (uint32_t w = 0; w < 8; ++w)
                 if (w < ncopy) sp.arena[off + w] = s_slot[w * 64 + lane];
