@@ -108,8 +108,17 @@ __global__ void __launch_bounds__(256, 2)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     bool walk_general[2] = {false, false};  // per channel type: the last pass had a symbol-table miss (walk_nonzeros)
-    for (uint32_t p = pstart; p < pairs_total; p += pstep) {
-        STAMP(7);
+    // One pass = one (frame, tile, pass) of this wave's share.  Its coordinates are worked out one pass AHEAD, and the
+    // first row pair of the next pass is requested before the entropy walk of the current one: the load (an HBM miss for
+    // the first of a tile's three channel waves) lands during the walk instead of stalling the next pass at its first
+    // instruction, and because vmcnt retires in issue order it does not wait behind this pass's scattered string stores.
+    struct Pass {
+        uint32_t frame, tile, chan;
+        uint32_t bxs[4], bys[4];
+        bool fast;
+    };
+    auto locate = [&](uint32_t p) -> Pass {
+        Pass ps;
         uint32_t frame, tile, chan;
         if (xcd_map) {
             const uint32_t pf = tiles_x * kPasses;
@@ -123,17 +132,10 @@ __global__ void __launch_bounds__(256, 2)
             tile = q / kPasses;
             chan = q % kPasses;
         }
-        // `chan` is the pass; the colour component differs from it only in 4:2:0 (passes 0..3 = luma)
-        const uint32_t comp = S420 ? (chan < 4u ? 0u : chan - 3u) : chan;
-        const bool luma420 = S420 && chan < 4u, chroma420 = S420 && chan >= 4u;
-        const uint32_t ct = comp ? 1u : 0u;
-        const uint8_t* f = rgb + (size_t)frame * g.frame_stride;
-        const bool avg = !STD && (comp != 0) && (g.flags & 1u);  // standard mode never replicates chroma means
-        const size_t us_base = (((size_t)frame * g.tiles + tile) * kPasses + chan) * 64;
+        const bool luma420 = S420 && chan < 4u;
 
         // block coordinates of this lane's four blocks (16j + n), and whether the whole tile
         // lies inside the image (no mirror padding)
-        uint32_t bxs[4], bys[4];
         bool interior = true;
         if constexpr (S420) {
             // MCU of this lane's unit in sub-tile j: luma pass s: 16 s + 4 j + n / 4 (block k = n & 3 of it),
@@ -148,12 +150,12 @@ __global__ void __launch_bounds__(256, 2)
                     my = g.N / g.nmx - 1;
                 }
                 if (luma420) {
-                    bxs[j] = 2 * mx + (n & 1);
-                    bys[j] = 2 * my + ((n >> 1) & 1);
-                    interior = interior && (bxs[j] * 8 + 8 <= g.W) && (bys[j] * 8 + 8 <= g.H);
+                    ps.bxs[j] = 2 * mx + (n & 1);
+                    ps.bys[j] = 2 * my + ((n >> 1) & 1);
+                    interior = interior && (ps.bxs[j] * 8 + 8 <= g.W) && (ps.bys[j] * 8 + 8 <= g.H);
                 } else {
-                    bxs[j] = mx;
-                    bys[j] = my;
+                    ps.bxs[j] = mx;
+                    ps.bys[j] = my;
                     interior = interior && (mx * 16 + 16 <= g.W) && (my * 16 + 16 <= g.H);
                 }
                 m += step;
@@ -173,8 +175,8 @@ __global__ void __launch_bounds__(256, 2)
                     bx = g.nbx - 1;
                     by = g.N / g.nbx - 1;
                 }
-                bxs[j] = bx;
-                bys[j] = by;
+                ps.bxs[j] = bx;
+                ps.bys[j] = by;
                 interior = interior && (bx * 8 + 8 <= g.W) && (by * 8 + 8 <= g.H);
                 bx += 16;
                 while (bx >= g.nbx) {
@@ -183,7 +185,34 @@ __global__ void __launch_bounds__(256, 2)
                 }
             }
         }
-        const bool fast = g.fast_rows && __all(interior);
+        ps.fast = g.fast_rows && __all(interior);
+        ps.frame = frame, ps.tile = tile, ps.chan = chan;
+        return ps;
+    };
+    uint32_t raw[12];  // raw RGB of the row pair to convert next (fast path)
+    auto request_first_rows = [&](const Pass& ps) {
+        const bool chroma420 = S420 && ps.chan >= 4u;
+        if (ps.fast && !chroma420) load_raw_rowpair(rgb + (size_t)ps.frame * g.frame_stride, g, ps.bxs[0], ps.bys[0], gq, raw);
+    };
+    Pass cur{}, nxt{};
+    if (pstart < pairs_total) {
+        cur = locate(pstart);
+        request_first_rows(cur);
+    }
+    for (uint32_t p = pstart; p < pairs_total; p += pstep) {
+        STAMP(7);
+        const uint32_t frame = cur.frame, tile = cur.tile, chan = cur.chan;
+        // `chan` is the pass; the colour component differs from it only in 4:2:0 (passes 0..3 = luma)
+        const uint32_t comp = S420 ? (chan < 4u ? 0u : chan - 3u) : chan;
+        const bool luma420 = S420 && chan < 4u, chroma420 = S420 && chan >= 4u;
+        const uint32_t ct = comp ? 1u : 0u;
+        const uint8_t* f = rgb + (size_t)frame * g.frame_stride;
+        const bool avg = !STD && (comp != 0) && (g.flags & 1u);  // standard mode never replicates chroma means
+        const size_t us_base = (((size_t)frame * g.tiles + tile) * kPasses + chan) * 64;
+        uint32_t bxs[4], bys[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bxs[j] = cur.bxs[j], bys[j] = cur.bys[j];
+        const bool fast = cur.fast;
 
         STAMP(0);
         // Issue arbitration is oldest-first, and the two workgroups of a CU are dispatched in grid
@@ -201,10 +230,8 @@ __global__ void __launch_bounds__(256, 2)
         s_mhi[lane] = 0;
         __builtin_amdgcn_wave_barrier();
 
-        // raw RGB of unit-tile j+1 is fetched while unit-tile j is processed
-        uint32_t raw[12];
+        // raw RGB of unit-tile j+1 is fetched while unit-tile j is processed (that of unit-tile 0 was requested a pass ago)
         uint32_t dcsum = 0;  // sample sum of the block whose coefficient 0 this lane will form
-        if (fast && !chroma420) load_raw_rowpair(f, g, bxs[0], bys[0], gq, raw);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t bx = bxs[j], by = bys[j];
@@ -300,6 +327,10 @@ __global__ void __launch_bounds__(256, 2)
             atomicOr(&s_mhi[16 * j + n], nzhi << (4 * gq));
             if (amb) atomicOr(&s_mlo[16 * j + n], 1u);  // bit 0 (coefficient 0 is never walked) = "undecided unit"
             STAMP(6);
+        }
+        if (p + pstep < pairs_total) {  // wave-uniform
+            nxt = locate(p + pstep);
+            request_first_rows(nxt);
         }
         {
             // exact coefficient 0 of unit 16*gq + n.  Strict: c0 = fl(sum * SCALE_00), q0 = round(c0 / Q0)
@@ -405,6 +436,7 @@ __global__ void __launch_bounds__(256, 2)
         sp.meta[us_base + lane] = make_uint2(off, active ? ((aclen << 16) | ((uint32_t)dc & 0xffffu)) : 0u);
         __builtin_amdgcn_wave_barrier();
         STAMP(4);
+        cur = nxt;
     }
 #ifdef MI355_STAMPS
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wave_t1)::"memory");
