@@ -294,6 +294,22 @@ __device__ __forceinline__ bool put_dc(int diff, const uint32_t* __restrict__ dc
     return true;
 }
 
+// Wave-wide inclusive prefix sum / maximum with DPP row shifts and row broadcasts (6 VALU
+// instructions, no LDS round trips like __shfl).  Lane 63 ends up with the reduction.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_src(uint32_t v) {
+    // lanes without a valid source (or outside ROW_MASK) read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/) {
+    v += dpp_src<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_src<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_src<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_src<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_src<0x142, 0xa>(v);  // row_bcast:15 into rows 1, 3
+    v += dpp_src<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3
+    return v;
+}
 __device__ __forceinline__ void load_unit(const uint32_t* __restrict__ src, uint32_t (&c)[32]) {
 #pragma unroll
     for (int p = 0; p < 32; ++p) c[p] = src[p * 64];

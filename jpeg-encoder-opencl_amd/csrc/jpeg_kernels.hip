@@ -175,55 +175,75 @@ __global__ void __launch_bounds__(192)
 
 // ----------------------------------------------------------------------------
 // k_tile_scan: one workgroup per frame (NT = 256 threads, 1024 for frames with many tiles);
-// exclusive 64-bit scan of the tile sums (each thread owns a contiguous chunk of tiles).  Also zeroes
-// every output word that two tiles share (the emit/merge kernels OR into those), writes the frame's bit
-// count, checks the caller's capacity and -- for the screened pipeline, whose encode kernel
-// accumulates the tile sums with atomics -- re-arms the sums and counters.  The 256-thread form is
+// exclusive 64-bit scan of the tile sums, 4 NT tiles at a time: thread t takes tiles base + 4t .. + 3, so the sums are
+// read and the offsets written with (nearly) coalesced accesses (the next chunk's sums are requested before the current
+// chunk is scanned), a 32-bit DPP scan inside each wave, the wave totals through LDS, a 64-bit carry from chunk to chunk.
+// (Round 1 gave every thread a contiguous run of tiles: 64 dependent strided loads per thread on a 16384 x 16384 frame,
+// 0.19 ms = 8 % of that call.)  Also zeroes every output word that two tiles share (the emit/merge kernels OR into
+// those), writes the frame's bit count, checks the caller's capacity and -- for the screened pipeline, whose encode
+// kernel accumulates the tile sums with atomics -- re-arms the sums and counters.  The 256-thread form is
 // one wave per SIMD with few registers: it fits on a CU next to two resident workgroups of
 // k_screen_encode of another stream (a 1024-thread workgroup has to wait for a free slot).
+// A chunk's sums fit 32 bits: a tile is at most 384 units of at most 64 symbols of at most 27 bits (< 2^20 bits), a chunk 4096 tiles.
 // ----------------------------------------------------------------------------
 template <uint32_t NT>
 __global__ void __launch_bounds__(NT)
     k_tile_scan(Geom g, uint32_t* __restrict__ tile_bits, uint64_t* __restrict__ tile_off,
                 uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ frame_bits,
                 uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters, uint32_t rearm_tiles) {
-    __shared__ uint64_t s_wave[NT / 64];
+    constexpr uint32_t kPer = 4;  // consecutive tiles per thread and chunk
+    __shared__ uint32_t s_wave[NT / 64];
     __builtin_amdgcn_s_setprio(3);  // short, on the stream's critical path, resident next to encode kernels
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t frame = blockIdx.x;
     uint32_t* tb = tile_bits + (size_t)frame * g.tiles;
     uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
     uint32_t* outw = reinterpret_cast<uint32_t*>(out + (size_t)frame * out_stride);
-    const uint32_t per = (g.tiles + NT - 1u) / NT;
-    const uint32_t lo = tid * per < g.tiles ? tid * per : g.tiles;
-    const uint32_t hi = lo + per < g.tiles ? lo + per : g.tiles;
     // restart intervals (standard mode, MI355_F_RESTART): every tile starts on a byte boundary
     const uint32_t pad = (g.flags & 8u) ? 7u : 0u;
-    uint64_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += (tb[i] + pad) & ~pad;
-    uint64_t incl = sum;
+    uint64_t carry = 0;  // bits of all tiles before this chunk (the same in every thread)
+    uint32_t next[kPer];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint64_t n = __shfl_up(incl, d);
-        if ((int)lane >= d) incl += n;
+    for (uint32_t k = 0; k < kPer; ++k) next[k] = tid * kPer + k < g.tiles ? tb[tid * kPer + k] : 0u;
+    for (uint32_t base = 0; base < g.tiles; base += NT * kPer) {  // uniform trip count: DPP scans need every lane
+        const uint32_t i0 = base + tid * kPer;
+        uint32_t v[kPer], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            v[k] = i0 + k < g.tiles ? ((next[k] + pad) & ~pad) : 0u;
+            sum += v[k];
+            const uint32_t in = i0 + NT * kPer + k;
+            next[k] = in < g.tiles ? tb[in] : 0u;
+        }
+        const uint32_t incl = wave_incl_scan(sum, lane);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t pre = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < NT / 64; ++w) {
+            const uint32_t t = s_wave[w];
+            total += t;
+            if (w < wave) pre += t;
+        }
+        __syncthreads();  // s_wave is rewritten by the next chunk
+        uint64_t run = carry + pre + (incl - sum);  // exclusive offset of tile i0
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t i = i0 + k;
+            if (i < g.tiles) {
+                to[i] = run;
+                // word shared with the previous tile: both sides OR into it
+                if (i > 0 && (run & 31) && (run >> 5) * 4 + 4 <= out_stride) outw[run >> 5] = 0;
+                if (rearm_tiles) tb[i] = 0;
+            }
+            run += v[k];
+        }
+        carry += total;
     }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint64_t pre = 0;
-    for (uint32_t w = 0; w < wave; ++w) pre += s_wave[w];
-    uint64_t run = pre + incl - sum;  // exclusive offset of this thread's first tile
-    for (uint32_t i = lo; i < hi; ++i) {
-        to[i] = run;
-        // word shared with the previous tile: both sides OR into it
-        if (i > 0 && (run & 31) && (run >> 5) * 4 + 4 <= out_stride) outw[run >> 5] = 0;
-        run += (tb[i] + pad) & ~pad;
-        if (rearm_tiles) tb[i] = 0;
-    }
-    if (tid == NT - 1) {
-        const uint64_t total = pre + incl;
-        to[g.tiles] = total;
-        frame_bits[frame] = total;
-        if (((total + 31) >> 5) * 4 > out_stride) atomicOr(status, 2u);  // MI355_E_CAPACITY
+    if (tid == 0) {
+        to[g.tiles] = carry;
+        frame_bits[frame] = carry;
+        if (((carry + 31) >> 5) * 4 > out_stride) atomicOr(status, 2u);  // MI355_E_CAPACITY
         // the screened pipeline's arena counter is consumed by now: re-arm it
         if (reset_counters && frame == 0) reset_counters[0] = 0;
     }

@@ -416,22 +416,6 @@ __device__ __forceinline__ uint32_t symbol_slow(int v, uint32_t r, const uint32_
     return (m << (32u - t)) | t;
 }
 
-// Wave-wide inclusive prefix sum / maximum with DPP row shifts and row broadcasts (6 VALU
-// instructions, no LDS round trips like __shfl).  Lane 63 ends up with the reduction.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_src(uint32_t v) {
-    // lanes without a valid source (or outside ROW_MASK) read 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/) {
-    v += dpp_src<0x111, 0xf>(v);  // row_shr:1
-    v += dpp_src<0x112, 0xf>(v);  // row_shr:2
-    v += dpp_src<0x114, 0xf>(v);  // row_shr:4
-    v += dpp_src<0x118, 0xf>(v);  // row_shr:8
-    v += dpp_src<0x142, 0xa>(v);  // row_bcast:15 into rows 1, 3
-    v += dpp_src<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3
-    return v;
-}
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {  // uniform result
     return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63);
 }
@@ -609,7 +593,7 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
 // fv = fma(acc4, 2^16, fl(t)), zf = fl(fv * fl(2^-23/Q)): three roundings, |zf - Y' 2^-23/Q| <= |z| 2^-22 +
 // 2^-18/Q.  rn = nearest integer of zf by the 1.5 * 2^23 trick, d = zf - rn exact.  The quantised value is
 // rn whenever |d| + |zf| 2^-21 < 0.5 - (E1_R + 2^-18 + delta_R)/Q - 2^-22  (threshold rounded down on the host).
-// Second look (wave-uniform, a few per cent of the groups): the two low digits are fetched and all five
+// Second look (wave-uniform, 0.2 % of the groups on q50 noise): the two low digits are fetched and all five
 // give y2 = Lt p exactly in fp64; threshold 0.5 - delta_R/Q (1 + 1e-6) - 2^-38.  Standard mode is DEFINED by
 // its integer map and decides exactly there.  What is still undecided sets `amb`: the exact ordered fp64
 // chain then recomputes the unit (exact_unit_wave) -- that chain remains the arbiter.

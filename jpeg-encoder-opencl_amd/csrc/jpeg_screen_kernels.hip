@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(256, 2)
                 uint32_t cur[12];
 #pragma unroll
                 for (int i = 0; i < 12; ++i) cur[i] = raw[i];
-                if (j < 3) load_raw_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, raw);
+                if (j < 3) load_raw_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, raw);  // (two pairs in flight: -1 %)
 #ifdef MI355_DIAG_NOTIE  // timing experiment only (wrong in 1 luma sample of 1000): luma without the tie check
                 if (comp == 0) convert_rowpair<0, STD, true>(cur, false, pk);
 #else
