@@ -79,6 +79,9 @@ __global__ void __launch_bounds__(256, 2)
     // (rare) second look and are fetched on demand.
     v4i A[4][kLookDigits];
     load_look_fragments(sp, lane, A);
+    // quantiser divisors of coefficient 0, read once: a load per pass would sit behind everything the wave has in flight
+    // (vmcnt retires in issue order), the next pass's first rows included
+    const double q0_luma = sp.qd[0], q0_chroma = sp.qd[64];
     __syncthreads();
 
     // Work distribution.  With a grid that is a multiple of 8 workgroups, the waves of XCD x
@@ -339,12 +342,12 @@ __global__ void __launch_bounds__(256, 2)
             int q0;
             if constexpr (STD) {
                 const int sl = (int)dcsum - 8192;
-                const uint32_t Q0 = (uint32_t)sp.qd[ct * 64], a0 = (uint32_t)(sl < 0 ? -sl : sl);
+                const uint32_t Q0 = (uint32_t)(ct ? q0_chroma : q0_luma), a0 = (uint32_t)(sl < 0 ? -sl : sl);
                 const int n0 = (int)((a0 + 4u * Q0) / (8u * Q0));
                 q0 = sl < 0 ? -n0 : n0;
             } else {
                 const double c0 = (double)((int)dcsum - 8192) * kScale00;
-                q0 = (int)__builtin_round(c0 / sp.qd[ct * 64]);
+                q0 = (int)__builtin_round(c0 / (ct ? q0_chroma : q0_luma));
             }
             tb16[row_unit_off(16 * gq + n)] = (int16_t)q0;
         }
