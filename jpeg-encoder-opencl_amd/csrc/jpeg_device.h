@@ -98,7 +98,14 @@ hipError_t launch_unit_sizes(const Geom& g, uint32_t n_frames, const uint32_t* c
 hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, uint32_t* tile_bits,
                             uint64_t* tile_off, uint8_t* out, uint64_t out_stride,
                             uint64_t* frame_bits, uint32_t* status, uint32_t* reset_counters,
-                            bool rearm_tiles, hipStream_t s);
+                            bool rearm_tiles, uint64_t* chunk_tot, hipStream_t s);
+// Frames above 8192 tiles are scanned by scan_chunks(g) workgroups each (4096 tiles per chunk); their totals need
+// scan_chunks(g) words of scratch per frame (`chunk_tot`; nullptr: one workgroup per frame).
+inline uint32_t scan_chunks(const Geom& g) { return g.tiles > 8192 ? (g.tiles + 4095) / 4096 : 0; }
+// entries of the tile-offset workspace of a batch: [frame][tiles + 1] offsets, then the scan scratch
+inline size_t tile_off_entries(const Geom& g, uint32_t n_frames) {
+    return ((size_t)g.tiles + 1 + scan_chunks(g)) * n_frames;
+}
 hipError_t launch_emit(const Geom& g, uint32_t n_frames, const uint32_t* coefs, const uint32_t* lut,
                        const uint32_t* unit_off, const uint64_t* tile_off, uint8_t* out,
                        uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,

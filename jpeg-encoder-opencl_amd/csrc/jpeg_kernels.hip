@@ -250,6 +250,84 @@ __global__ void __launch_bounds__(NT)
 }
 
 // ----------------------------------------------------------------------------
+// Frames above 8192 tiles: the same scan by several workgroups per frame, in two launches.  k_tile_chunks: workgroup
+// (c, frame) scans chunk c (4096 tiles: 1024 threads x 4) on its own -- offsets relative to the chunk into `tile_off`,
+// the chunk's total into `chunk_tot` -- and re-arms the sums; k_tile_fix adds the totals of the chunks in front (at
+// most 16 of them), zeroes the shared words, and the last chunk's first thread closes the frame.  One workgroup for
+// all 65,536 tiles of a 16384 x 16384 frame is bound by its own stores: 0.084 ms; this pair: see DESIGN.md.
+// ----------------------------------------------------------------------------
+constexpr uint32_t kChunkTiles = 4096;
+__global__ void __launch_bounds__(1024)
+    k_tile_chunks(Geom g, uint32_t* __restrict__ tile_bits, uint64_t* __restrict__ tile_off,
+                  uint64_t* __restrict__ chunk_tot, uint32_t chunks, uint32_t rearm_tiles) {
+    __shared__ uint32_t s_wave[16];
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c = blockIdx.x, frame = blockIdx.y;
+    uint32_t* tb = tile_bits + (size_t)frame * g.tiles;
+    uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
+    const uint32_t pad = (g.flags & 8u) ? 7u : 0u;
+    const uint32_t i0 = c * kChunkTiles + tid * 4;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        v[k] = i0 + k < g.tiles ? ((tb[i0 + k] + pad) & ~pad) : 0u;
+        sum += v[k];
+    }
+    const uint32_t incl = wave_incl_scan(sum, lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t pre = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; ++w) {
+        const uint32_t t = s_wave[w];
+        total += t;
+        if (w < wave) pre += t;
+    }
+    uint32_t run = pre + (incl - sum);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (i0 + k < g.tiles) {
+            to[i0 + k] = run;  // relative to the chunk; k_tile_fix makes it absolute
+            if (rearm_tiles) tb[i0 + k] = 0;
+        }
+        run += v[k];
+    }
+    if (tid == 0) chunk_tot[(size_t)frame * chunks + c] = total;
+}
+__global__ void __launch_bounds__(1024)
+    k_tile_fix(Geom g, uint64_t* __restrict__ tile_off, const uint64_t* __restrict__ chunk_tot, uint32_t chunks,
+               uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ frame_bits,
+               uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters) {
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t c = blockIdx.x, frame = blockIdx.y;
+    uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
+    uint32_t* outw = reinterpret_cast<uint32_t*>(out + (size_t)frame * out_stride);
+    const uint64_t* ct = chunk_tot + (size_t)frame * chunks;
+    uint64_t before = 0;
+    for (uint32_t k = 0; k < c; ++k) before += ct[k];
+    const uint32_t i0 = c * kChunkTiles + tid * 4;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t i = i0 + k;
+        if (i < g.tiles) {
+            const uint64_t run = before + to[i];
+            to[i] = run;
+            // word shared with the previous tile: both sides OR into it
+            if (i > 0 && (run & 31) && (run >> 5) * 4 + 4 <= out_stride) outw[run >> 5] = 0;
+        }
+    }
+    if (c + 1 == chunks && tid == 0) {
+        const uint64_t total = before + ct[c];
+        to[g.tiles] = total;
+        frame_bits[frame] = total;
+        if (((total + 31) >> 5) * 4 > out_stride) atomicOr(status, 2u);  // MI355_E_CAPACITY
+        if (reset_counters && frame == 0) reset_counters[0] = 0;
+    }
+}
+
+// ----------------------------------------------------------------------------
 // k_emit: workgroup = one tile (3 waves = 3 channels, lane = block).  The tile's
 // 192 units are contiguous in the scan, so its bits are assembled in LDS
 // (big-endian 32-bit words, LDS atomic OR) and written out as coalesced words;
@@ -404,13 +482,20 @@ hipError_t launch_unit_sizes(const Geom& g, uint32_t n_frames, const uint32_t* c
 hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, uint32_t* tile_bits,
                             uint64_t* tile_off, uint8_t* out, uint64_t out_stride,
                             uint64_t* frame_bits, uint32_t* status, uint32_t* reset_counters,
-                            bool rearm_tiles, hipStream_t s) {
-    if (g.tiles <= 8192)
+                            bool rearm_tiles, uint64_t* chunk_tot, hipStream_t s) {
+    if (g.tiles <= 8192) {
         hipLaunchKernelGGL(k_tile_scan<256>, dim3(n_frames), dim3(256), 0, s, g, tile_bits, tile_off, out,
                            out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u);
-    else
+    } else if (chunk_tot) {  // several workgroups per frame, two launches
+        const uint32_t chunks = scan_chunks(g);
+        hipLaunchKernelGGL(k_tile_chunks, dim3(chunks, n_frames), dim3(1024), 0, s, g, tile_bits, tile_off, chunk_tot,
+                           chunks, rearm_tiles ? 1u : 0u);
+        hipLaunchKernelGGL(k_tile_fix, dim3(chunks, n_frames), dim3(1024), 0, s, g, tile_off, chunk_tot, chunks, out,
+                           out_stride, frame_bits, status, reset_counters);
+    } else {
         hipLaunchKernelGGL(k_tile_scan<1024>, dim3(n_frames), dim3(1024), 0, s, g, tile_bits, tile_off, out,
                            out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u);
+    }
     return hipGetLastError();
 }
 hipError_t launch_emit(const Geom& g, uint32_t n_frames, const uint32_t* coefs, const uint32_t* lut,

@@ -363,7 +363,7 @@ int ensure_workspace(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames) {
     if ((e = ensure(c->d_coefs, c->coefs_cap, coef_dwords(g) * n_frames))) return e;
     if ((e = ensure(c->d_unit_off, c->unit_off_cap, unit_off_words(g) * n_frames))) return e;
     if ((e = ensure(c->d_tile_bits, c->tiles_cap, (size_t)g.tiles * n_frames, true))) return e;
-    if ((e = ensure(c->d_tile_off, c->tile_off_cap, ((size_t)g.tiles + 1) * n_frames))) return e;
+    if ((e = ensure(c->d_tile_off, c->tile_off_cap, tile_off_entries(g, n_frames)))) return e;
     return MI355_OK;
 }
 
@@ -481,7 +481,8 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
     record(c, 2, s);
     // invariant: d_tile_bits is all zero between API calls (the screened pipeline accumulates into it)
     HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
-                             c->d_status, nullptr, true, s));
+                             c->d_status, nullptr, true,
+                             scan_chunks(g) ? c->d_tile_off + ((size_t)g.tiles + 1) * n_frames : nullptr, s));
     record(c, 3, s);
     HIP_TRY(launch_emit(g, n_frames, c->d_coefs, c->d_lut, c->d_unit_off, c->d_tile_off, d_out,
                         out_stride, c->d_status, c->emit_lds_words, s));
@@ -509,12 +510,13 @@ ScreenParams part_params(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p) {
 }
 
 int launch_tails(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p, const ScreenParams& sp, uint8_t* d_out,
-                 size_t out_stride, uint64_t* d_bits, hipStream_t s, bool rec) {
+                 size_t out_stride, uint64_t* d_bits, hipStream_t s, bool rec, uint32_t batch_frames) {
     HIP_TRY(launch_dc_heads(g, p.nf, sp, s));
     if (rec) record(c, 2, s);  // slot [1,2] = DC heads (the other tile sums are accumulated by the encode kernel itself)
     HIP_TRY(launch_tile_scan(g, p.nf, sp.tile_bits, c->d_tile_off + (size_t)p.f0 * (g.tiles + 1),
                              d_out + (size_t)p.f0 * out_stride, out_stride, d_bits + p.f0, c->d_status, sp.counters,
-                             true, s));
+                             true, scan_chunks(g) ? c->d_tile_off + ((size_t)g.tiles + 1) * batch_frames + (size_t)p.f0 * scan_chunks(g) : nullptr,
+                             s));
     if (rec) record(c, 3, s);
     HIP_TRY(launch_merge(g, p.nf, sp.meta, sp.arena, sp.lut, c->d_tile_off + (size_t)p.f0 * (g.tiles + 1),
                          d_out + (size_t)p.f0 * out_stride, out_stride, c->d_status, c->emit_lds_words, s));
@@ -568,11 +570,11 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
                                      c->screen_waves, s));
         if (i + 1 == nparts) {  // the last part's tails stay on the caller's stream
             record(c, 1, s);
-            if ((e = launch_tails(c, g, part[i], sp, d_out, out_stride, d_bits, s, nparts == 1))) return e;
+            if ((e = launch_tails(c, g, part[i], sp, d_out, out_stride, d_bits, s, nparts == 1, n_frames))) return e;
         } else {  // tails on the side stream, under the next part's block encode
             HIP_TRY(hipEventRecord(c->ev_half, s));
             HIP_TRY(hipStreamWaitEvent(c->side, c->ev_half, 0));
-            if ((e = launch_tails(c, g, part[i], sp, d_out, out_stride, d_bits, c->side, false))) return e;
+            if ((e = launch_tails(c, g, part[i], sp, d_out, out_stride, d_bits, c->side, false, n_frames))) return e;
         }
     }
     if (nparts > 1) {
@@ -598,7 +600,7 @@ FusedParams fused_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, ui
     const size_t granules = (size_t)g.tiles * n_frames * 4;
     const bool fresh = granules > c->rec_cap || !c->d_rec;
     if ((e = ensure(c->d_rec, c->rec_cap, granules, true)) || (e = ensure(c->d_ovf, c->ovf_cap, fused_ovf_words(wgs))) ||
-        (e = ensure(c->d_tile_off, c->tile_off_cap, ((size_t)g.tiles + 1) * n_frames)) ||
+        (e = ensure(c->d_tile_off, c->tile_off_cap, tile_off_entries(g, n_frames))) ||
         (e = ensure(c->d_ticket, c->ticket_cap, ((size_t)n_frames + 3) & ~(size_t)3))) {
         *err = e;
         return fp;
@@ -891,7 +893,7 @@ int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t
         // only unit_off / tile arrays of the classic workspace are needed
         if ((e = ensure(c->d_unit_off, c->unit_off_cap, unit_off_words(g) * n_frames))) return e;
         if ((e = ensure(c->d_tile_bits, c->tiles_cap, (size_t)g.tiles * n_frames, true))) return e;
-        if ((e = ensure(c->d_tile_off, c->tile_off_cap, ((size_t)g.tiles + 1) * n_frames))) return e;
+        if ((e = ensure(c->d_tile_off, c->tile_off_cap, tile_off_entries(g, n_frames)))) return e;
         return run_screened(c, g, n_frames, (const uint8_t*)d_rgb, (uint8_t*)d_out, out_stride, d_bits, s);
     }
     if ((e = ensure_workspace(c, g, n_frames))) return e;
