@@ -152,8 +152,9 @@ struct mi355_jpeg_ctx {
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
     uint8_t* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // scratch of the stage-by-stage entry points
     size_t stage_cap[4] = {0, 0, 0, 0};
-    // single-launch pipeline (jpeg_fused_kernels.hip)
-    int pipeline = 0;               // 0: block-encode kernel + merge kernel; 1 (MI355_JPEG_PIPELINE=fused): the single-launch kernel k_encode_fused (strict and standard 4:4:4)
+    // single-launch pipeline (jpeg_tile_kernels.hip)
+    int pipeline = 1;               // 1 (default; MI355_JPEG_PIPELINE=tile): the single-launch kernel k_encode_tile (strict and standard 4:4:4);
+                                    // 0 (MI355_JPEG_PIPELINE=launches, and always for 4:2:0): block-encode kernel + three tail kernels
     unsigned long long* d_rec = nullptr;
     size_t rec_cap = 0;             // granules
     uint32_t* d_ticket = nullptr;   // [frames] per-frame ticket counters
@@ -161,7 +162,7 @@ struct mi355_jpeg_ctx {
     uint32_t* d_ovf = nullptr;
     size_t ovf_cap = 0;             // words
     uint32_t epoch = 0;
-    uint32_t fused_wgs = 256;       // workgroups of k_encode_fused (one per CU)
+    uint32_t tile_wgs = 256;        // workgroups of k_encode_tile (one per CU)
     uint2* d_meta = nullptr;
     size_t meta_cap = 0;
     uint32_t* d_arena = nullptr;
@@ -368,6 +369,7 @@ int ensure_workspace(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames) {
 }
 
 constexpr size_t kMaxEventSets = 1u << 16;
+constexpr unsigned long kEmitWordsMax = 4096;  // kEmitLdsWords (jpeg_devfn.h): the bit-assembly window of k_emit / k_merge
 
 // slot 0 opens a new event set for this call
 // workspace of the screened pipeline; arena_words: capacity for the AC blobs
@@ -587,57 +589,45 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     return MI355_OK;
 }
 
-// Single-launch pipeline: k_encode_fused.  Event slots: [0,1] the kernel; the other slots coincide with 1.
-FusedParams fused_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint32_t wgs, uint8_t* d_out, size_t out_stride,
-                         uint64_t* d_bits, int* err, hipStream_t s) {
-    FusedParams fp;
-    memset(&fp, 0, sizeof fp);
-    *err = MI355_OK;
+// Single-launch pipeline: k_encode_tile (jpeg_tile_kernels.hip).  Event slots: [0,1] the kernel; the other slots
+// coincide with 1.  Device memory besides the caller's buffers: 64 bytes of hand-off granules per tile, one ticket
+// counter per frame, 13.5 KiB of string overflow area per resident wave -- nothing that scales with the output capacity.
+int run_tile(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t* d_rgb, uint8_t* d_out, size_t out_stride,
+             uint64_t* d_bits, hipStream_t s) {
+    const uint32_t wgs = tile_grid(g, n_frames, c->tile_wgs);
+    TileParams tp;
+    memset(&tp, 0, sizeof tp);
     ArenaPlan none{1, 0, 0};
-    fp.sp = screen_params(c, g, n_frames, none, nullptr);
-    fp.sp.prio_from_wg = 0xFFFFFFFFu;
+    tp.sp = screen_params(c, g, n_frames, none, nullptr);
+    tp.sp.prio_from_wg = 0xFFFFFFFFu;
     int e;
-    const size_t granules = (size_t)g.tiles * n_frames * 4;
+    const size_t granules = tile_rec_granules(g, n_frames);
+    const size_t tickets = ((size_t)n_frames + 3) & ~(size_t)3;
     const bool fresh = granules > c->rec_cap || !c->d_rec;
-    if ((e = ensure(c->d_rec, c->rec_cap, granules, true)) || (e = ensure(c->d_ovf, c->ovf_cap, fused_ovf_words(wgs))) ||
+    if ((e = ensure(c->d_rec, c->rec_cap, granules, true)) || (e = ensure(c->d_ovf, c->ovf_cap, tile_ovf_words(wgs))) ||
         (e = ensure(c->d_tile_off, c->tile_off_cap, tile_off_entries(g, n_frames))) ||
-        (e = ensure(c->d_ticket, c->ticket_cap, ((size_t)n_frames + 3) & ~(size_t)3))) {
-        *err = e;
-        return fp;
-    }
+        (e = ensure(c->d_ticket, c->ticket_cap, tickets)))
+        return e;
     // the per-frame ticket counters start from zero in every launch (a memset node in stream order; a multiple of 16 bytes)
-    if (hipMemsetAsync(c->d_ticket, 0, (((size_t)n_frames + 3) & ~(size_t)3) * sizeof(uint32_t), s) != hipSuccess) *err = MI355_E_ALLOC;
+    HIP_TRY(hipMemsetAsync(c->d_ticket, 0, tickets * sizeof(uint32_t), s));
     // every launch tags its granules with a new epoch; records of earlier launches never match.  A fresh
     // (zeroed) record array can start over; at the wrap the array is cleared in stream order.
     if (fresh) c->epoch = 0;
     if (++c->epoch > 0xFFFFu) {
-        if (hipMemsetAsync(c->d_rec, 0, c->rec_cap * sizeof(unsigned long long), s) != hipSuccess) *err = MI355_E_ALLOC;
+        HIP_TRY(hipMemsetAsync(c->d_rec, 0, c->rec_cap * sizeof(unsigned long long), s));
         c->epoch = 1;
     }
-    fp.rec = c->d_rec;
-    fp.ticket = c->d_ticket;
-    fp.epoch = c->epoch;
-    {
-        static const char* dbg = getenv("MI355_JPEG_FUSED_DEBUG");
-        fp.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
-    }
-    fp.ovf = c->d_ovf;
-    fp.out = d_out;
-    fp.out_stride = out_stride;
-    fp.frame_bits = d_bits;
-    fp.tile_off = c->d_tile_off;
-    return fp;
-}
-
-int run_fused(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t* d_rgb, uint8_t* d_out, size_t out_stride,
-              uint64_t* d_bits, hipStream_t s) {
-    const uint32_t wgs = fused_grid(g, n_frames, c->fused_wgs);
-    int e;
-    FusedParams fp = fused_params(c, g, n_frames, wgs, d_out, out_stride, d_bits, &e, s);
-    if (e) return e;
+    tp.rec = c->d_rec;
+    tp.ticket = c->d_ticket;
+    tp.epoch = c->epoch;
+    tp.ovf = c->d_ovf;
+    tp.out = d_out;
+    tp.out_stride = out_stride;
+    tp.frame_bits = d_bits;
+    tp.tile_off = c->d_tile_off;
     record(c, 0, s);
     c->last_launches = 1;
-    HIP_TRY(launch_encode_fused(g, n_frames, d_rgb, fp, false, wgs, s));
+    HIP_TRY(launch_encode_tile(g, n_frames, d_rgb, tp, wgs, s));
     record(c, 1, s);
     record(c, 2, s);
     record(c, 3, s);
@@ -645,23 +635,8 @@ int run_fused(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t
     return MI355_OK;
 }
 
-// Stage probes through the same kernel: coefficients into the tiled workspace layout, samples into d_samples;
-// no output buffer (nothing is written).
-int run_fused_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, uint8_t* d_samples, hipStream_t s) {
-    const uint32_t wgs = fused_grid(g, 1, c->fused_wgs);
-    int e;
-    if ((e = ensure(c->d_bits, c->bits_cap, (size_t)2))) return e;
-    FusedParams fp = fused_params(c, g, 1, wgs, nullptr, 0, c->d_bits + 1, &e, s);
-    if (e) return e;
-    fp.sp.coefs = c->d_coefs;
-    fp.sp.samples = d_samples;
-    HIP_TRY(launch_encode_fused(g, 1, d_rgb, fp, true, wgs, s));
-    return MI355_OK;
-}
-
 // Screened transform only (stage probes): coefficients into the tiled workspace layout.
 int run_screened_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, uint8_t* d_samples, hipStream_t s) {
-    if (c->pipeline == 1 && !is420(g)) return run_fused_probe(c, g, d_rgb, d_samples, s);
     ArenaPlan plan = plan_arena(c, g, 1, unit_count(g) * 54);
     if (plan.total_words > 0xFFFFFFFFull) return MI355_E_ARG;
     int e;
@@ -676,6 +651,57 @@ int run_screened_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, u
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, 2 * sizeof(uint32_t), s));
     HIP_TRY(hipMemsetAsync(c->d_tile_bits, 0, (size_t)g.tiles * sizeof(uint32_t), s));
     return MI355_OK;
+}
+
+
+// Environment knobs (development / A-B switches).  Every one of them is validated: a value that does not parse, or
+// that could change RESULTS (accept margins narrower than proven, an unknown transform mode), fails the creation of
+// a context with MI355_E_ARG instead of being taken as 0.
+struct Knobs {
+    int transform_mode = 2;
+    uint32_t emit_lds_words = 4096;
+    double tau_scale = 1.0;
+    uint32_t batch_parts = 8;
+    int pipeline = 1;
+    uint32_t screen_waves = 0;  // 0: the device's default
+};
+bool read_knobs(Knobs* k) {
+    bool bad = false;
+    auto knob_uint = [&](const char* name, unsigned long lo, unsigned long hi, unsigned long* out) {
+        const char* v = getenv(name);
+        if (!v) return false;
+        char* end = nullptr;
+        const unsigned long x = strtoul(v, &end, 10);
+        if (!*v || *end || v[0] == '-' || v[0] == '+' || v[0] == ' ' || x < lo || x > hi) {
+            bad = true;
+            return false;
+        }
+        *out = x;
+        return true;
+    };
+    unsigned long kv = 0;
+    if (knob_uint("MI355_JPEG_TRANSFORM_MODE", 0, 2, &kv)) k->transform_mode = (int)kv;
+    if (knob_uint("MI355_JPEG_EMIT_LDS_WORDS", 0, kEmitWordsMax, &kv)) k->emit_lds_words = (uint32_t)kv;
+    if (const char* ts = getenv("MI355_JPEG_SCREEN_TAU_SCALE")) {
+        // widens the accept margins of the screened transform (tests force the second look and the exact chain with
+        // it).  Below 1 the margins would be narrower than the error bounds they stand for: refused, like anything
+        // that is not a finite number.
+        char* end = nullptr;
+        const double x = strtod(ts, &end);
+        if (!*ts || *end || !(x >= 1.0) || !std::isfinite(x)) bad = true;
+        else k->tau_scale = x;
+    }
+    if (knob_uint("MI355_JPEG_BATCH_PARTS", 1, 8, &kv)) k->batch_parts = (uint32_t)kv;
+    if (const char* pl = getenv("MI355_JPEG_PIPELINE")) {
+        if (!strcmp(pl, "tile")) k->pipeline = 1;
+        else if (!strcmp(pl, "launches")) k->pipeline = 0;
+        else bad = true;
+    }
+    if (knob_uint("MI355_JPEG_SCREEN_WAVES", 32, 8192, &kv)) {
+        if (kv & 31) bad = true;
+        else k->screen_waves = (uint32_t)kv;
+    }
+    return !bad;
 }
 
 int status_to_error(uint32_t st) {
@@ -716,6 +742,8 @@ int mi355_jpeg_device_count(void) {
 int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     if (!out) return MI355_E_ARG;
     *out = nullptr;
+    Knobs kn;
+    if (!read_knobs(&kn)) return MI355_E_ARG;  // before anything touches a device: testable anywhere
     int n = mi355_jpeg_device_count();
     if (n <= 0 || device_id < 0 || device_id >= n) return MI355_E_NO_DEVICE;
     HIP_TRY(hipSetDevice(device_id));
@@ -729,19 +757,13 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     }
     for (int i = 0; i < 64; ++i) c->qlum[i] = kQ50Lum[i], c->qchrom[i] = kQ50Chr[i];
     for (int t = 0; t < 4; ++t) reference_huffman(t, &c->huff[t]), reference_huffman(t, &c->huff_std[t], false);
-    const char* m = getenv("MI355_JPEG_TRANSFORM_MODE");
-    if (m) c->transform_mode = atoi(m);
-    const char* l = getenv("MI355_JPEG_EMIT_LDS_WORDS");
-    if (l) c->emit_lds_words = (uint32_t)atoi(l);
-    const char* ts = getenv("MI355_JPEG_SCREEN_TAU_SCALE");
-    if (ts) c->tau_scale = atof(ts);
-    const char* bp = getenv("MI355_JPEG_BATCH_PARTS");
-    if (bp && atoi(bp) >= 1 && atoi(bp) <= 8) c->batch_parts = (uint32_t)atoi(bp);
-    const char* pl = getenv("MI355_JPEG_PIPELINE");
-    if (pl) c->pipeline = !strcmp(pl, "fused") ? 1 : 0;
-    if (c->n_cus > 0) c->fused_wgs = (uint32_t)c->n_cus;
-    const char* sw = getenv("MI355_JPEG_SCREEN_WAVES");
-    if (sw && atoi(sw) > 0) c->screen_waves = (uint32_t)atoi(sw);
+    c->transform_mode = kn.transform_mode;
+    c->emit_lds_words = kn.emit_lds_words;
+    c->tau_scale = kn.tau_scale;
+    c->batch_parts = kn.batch_parts;
+    c->pipeline = kn.pipeline;
+    if (c->n_cus > 0) c->tile_wgs = (uint32_t)c->n_cus;
+    if (kn.screen_waves) (void)mi355_jpeg_set_encode_waves(c, kn.screen_waves);  // one place derives every grid from it
     int e = MI355_OK;
     if (hipMalloc((void**)&c->d_q, 128 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&c->d_qzz, 128 * sizeof(uint32_t)) != hipSuccess ||
@@ -833,7 +855,7 @@ int mi355_jpeg_set_huffman(mi355_jpeg_ctx* c, int table, const mi355_huff_table*
 int mi355_jpeg_set_encode_waves(mi355_jpeg_ctx* c, uint32_t waves) {
     if (!c || (waves != 0 && (waves < 32 || waves > 8192 || (waves & 31)))) return MI355_E_ARG;
     c->screen_waves = waves ? waves : (c->n_cus > 0 ? 8u * (uint32_t)c->n_cus : 2048u);
-    c->fused_wgs = c->screen_waves / 8u ? c->screen_waves / 8u : 1u;  // 8 waves per workgroup, one workgroup per CU
+    c->tile_wgs = c->screen_waves / 8u ? c->screen_waves / 8u : 1u;  // the same share of the device: one workgroup per CU
     return MI355_OK;
 }
 
@@ -888,7 +910,7 @@ int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
     if (c->transform_mode == 2 && c->pipeline == 1 && !is420(g))
-        return run_fused(c, g, n_frames, (const uint8_t*)d_rgb, (uint8_t*)d_out, out_stride, d_bits, s);
+        return run_tile(c, g, n_frames, (const uint8_t*)d_rgb, (uint8_t*)d_out, out_stride, d_bits, s);
     if (c->transform_mode == 2) {
         // only unit_off / tile arrays of the classic workspace are needed
         if ((e = ensure(c->d_unit_off, c->unit_off_cap, unit_off_words(g) * n_frames))) return e;

@@ -144,8 +144,9 @@ def test_category_error_matches_oracle(jpeg, enc):
 
 
 def test_emit_direct_path_equals_lds_path(jpeg, monkeypatch):
-    """Tiles whose bits exceed the LDS window take the direct-to-global path: force it
-    for every tile and compare."""
+    """Four-launch pipeline, k_merge: tiles whose bits exceed the LDS window take the direct-to-global path:
+    force it for every tile and compare."""
+    monkeypatch.setenv("MI355_JPEG_PIPELINE", "launches")
     rgb = ol.lcg_frame(640, 360, 3)
     ql, qc = ol.quant_tables(90)
     o = ol.oracle_encode(rgb, ql, qc, False)
@@ -745,12 +746,14 @@ def test_screen_counters_are_exposed(jpeg):
     e2.close()
 
 
-def test_single_launch_pipeline_is_bit_identical(jpeg, monkeypatch):
-    """MI355_JPEG_PIPELINE=fused: the single-launch kernel (block encode + in-kernel look-back scan + merge,
-    jpeg_fused_kernels.hip) against the oracle: ragged sizes, one-tile and many-tile frames, batches (several
-    frames per look-back group and several groups), high quality (strings longer than their LDS slot), the
-    capacity error, and the stage probes through the same kernel."""
-    monkeypatch.setenv("MI355_JPEG_PIPELINE", "fused")
+@pytest.mark.parametrize("pipeline", ["tile", "launches"])
+def test_both_pipelines_are_bit_identical(jpeg, monkeypatch, pipeline):
+    """MI355_JPEG_PIPELINE=tile (the default: the single-launch kernel of jpeg_tile_kernels.hip -- three waves per
+    tile, in-kernel look-back scan + merge) and =launches (block-encode kernel + three tail kernels) against the
+    oracle: ragged sizes, one-tile and many-tile frames, batches (several frames per look-back group and several
+    groups), high quality (strings longer than their LDS slot, tiles larger than the bit window), the capacity
+    error, and the stage probes."""
+    monkeypatch.setenv("MI355_JPEG_PIPELINE", pipeline)
     e2 = jpeg.Encoder(0)
     rng = np.random.default_rng(7)
     for (W, H, q, cds) in [(8, 8, 50, True), (253, 254, 50, True), (640, 360, 50, True), (1000, 37, 90, False),

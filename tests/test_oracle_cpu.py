@@ -245,3 +245,40 @@ def test_product_does_not_reference_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
                 text = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "oracle_lib" not in text and "jpeg_oracle" not in text and "liboracle" not in text, fn
+
+
+def test_exactness_knobs_are_refused_before_any_device_is_touched(monkeypatch):
+    """environment knobs that could silently void exactness (accept margins scaled below 1, values
+    that do not parse, unknown modes) fail mi355_jpeg_create with MI355_E_ARG -- checked before the device, so this
+    runs on CPU.  A valid environment gets past the knobs (and, here, stops at 'no device')."""
+    import ctypes as C
+    import importlib
+    monkeypatch.setenv("MI355_JPEG_NO_TORCH", "1")
+    jpeg = importlib.import_module("jpeg-encoder-opencl_amd")
+    L = jpeg.lib()
+
+    def create():
+        h = C.c_void_p()
+        rc = L.mi355_jpeg_create(0, C.byref(h))
+        if rc == 0:
+            L.mi355_jpeg_destroy(h)
+        return rc
+
+    base = create()
+    assert base in (jpeg.OK, jpeg.E_NO_DEVICE)
+    bad = [("MI355_JPEG_SCREEN_TAU_SCALE", v) for v in ("0.5", "0", "nan", "inf", "-1", "1e", "", "0.999999")] + \
+          [("MI355_JPEG_TRANSFORM_MODE", v) for v in ("3", "-1", "x", "2x", "")] + \
+          [("MI355_JPEG_EMIT_LDS_WORDS", v) for v in ("-1", "5000", "abc")] + \
+          [("MI355_JPEG_PIPELINE", v) for v in ("fused", "", "Tile")] + \
+          [("MI355_JPEG_SCREEN_WAVES", v) for v in ("33", "0", "100000")] + \
+          [("MI355_JPEG_BATCH_PARTS", v) for v in ("0", "9")]
+    for name, v in bad:
+        monkeypatch.setenv(name, v)
+        assert create() == jpeg.E_ARG, (name, v)
+        monkeypatch.delenv(name)
+    good = [("MI355_JPEG_SCREEN_TAU_SCALE", "1"), ("MI355_JPEG_SCREEN_TAU_SCALE", "1e6"), ("MI355_JPEG_TRANSFORM_MODE", "0"),
+            ("MI355_JPEG_PIPELINE", "launches"), ("MI355_JPEG_PIPELINE", "tile"), ("MI355_JPEG_SCREEN_WAVES", "1024")]
+    for name, v in good:
+        monkeypatch.setenv(name, v)
+        assert create() == base, (name, v)
+        monkeypatch.delenv(name)

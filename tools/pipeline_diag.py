@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development helper (GPU box): timing of the single-launch pipeline under diagnostic knobs.
-usage: fused_diag.py [frames] ; env MI355_JPEG_FUSED_DEBUG / MI355_JPEG_PIPELINE are read by the library."""
+usage: fused_diag.py [frames] ; env MI355_JPEG_PIPELINE are read by the library."""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,4 +31,4 @@ for k in (1, n):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     res["frames%d_us_per_frame" % k] = round(dt / k * 1e6, 2)
-print(json.dumps({"debug": os.environ.get("MI355_JPEG_FUSED_DEBUG"), "pipeline": os.environ.get("MI355_JPEG_PIPELINE"), **res}))
+print(json.dumps({"pipeline": os.environ.get("MI355_JPEG_PIPELINE"), **res}))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box helper: PMC passes over tools/fused_diag.py for the pipeline selected by the environment.
+# GPU box helper: PMC passes over tools/pipeline_diag.py for the pipeline selected by the environment.
 # usage: tools/pmc_diag.sh <outdir> [frames]
 set -e
 OUT=$1; N=${2:-32}
@@ -14,7 +14,7 @@ PASSES=(
 )
 i=0
 for P in "${PASSES[@]}"; do
-  rocprofv3 --pmc $P --output-format csv -d "$OUT/pass$i" -- python3 tools/fused_diag.py $N > "$OUT/pass$i.log" 2>&1
+  rocprofv3 --pmc $P --output-format csv -d "$OUT/pass$i" -- python3 tools/pipeline_diag.py $N > "$OUT/pass$i.log" 2>&1
   i=$((i+1))
 done
 python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.txt"

@@ -1,0 +1,10 @@
+#!/bin/bash
+# GPU box helper (round 3): parity of both pipelines, then their timing side by side.
+set -e -o pipefail
+OUT=gpurun_out/$1; mkdir -p "$OUT"
+cd "$GRAFT_REPO_ROOT"
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1 || { tail -60 "$OUT/pytest_gpu.log"; exit 1; }
+tail -3 "$OUT/pytest_gpu.log"
+for p in tile launches tile launches; do
+  MI355_JPEG_PIPELINE=$p timeout -k 10 300 python tools/pipeline_diag.py 128 | tee -a "$OUT/diag.log"
+done
