@@ -153,8 +153,9 @@ struct mi355_jpeg_ctx {
     uint8_t* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // scratch of the stage-by-stage entry points
     size_t stage_cap[4] = {0, 0, 0, 0};
     // single-launch pipeline (jpeg_tile_kernels.hip)
-    int pipeline = 1;               // 1 (default; MI355_JPEG_PIPELINE=tile): the single-launch kernel k_encode_tile (strict and standard 4:4:4);
-                                    // 0 (MI355_JPEG_PIPELINE=launches, and always for 4:2:0): block-encode kernel + three tail kernels
+    int pipeline = 0;               // 0 (default; MI355_JPEG_PIPELINE=launches, and always for 4:2:0): block-encode kernel + three tail kernels;
+                                    // 1 (MI355_JPEG_PIPELINE=tile): the single-launch kernel k_encode_tile (strict and standard 4:4:4) -- 1.05 x
+                                    // the algorithmic HBM bytes and no workspace, but 10 % slower on batches
     unsigned long long* d_rec = nullptr;
     size_t rec_cap = 0;             // granules
     uint32_t* d_ticket = nullptr;   // [frames] per-frame ticket counters
@@ -662,7 +663,7 @@ struct Knobs {
     uint32_t emit_lds_words = 4096;
     double tau_scale = 1.0;
     uint32_t batch_parts = 8;
-    int pipeline = 1;
+    int pipeline = 0;
     uint32_t screen_waves = 0;  // 0: the device's default
 };
 bool read_knobs(Knobs* k) {
@@ -931,7 +932,29 @@ int mi355_jpeg_sync(mi355_jpeg_ctx* c, void* stream) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
 #ifdef MI355_STAMPS
-    if (c->d_stamps && getenv("MI355_JPEG_DUMP_STAMPS")) {
+    if (c->d_stamps && getenv("MI355_JPEG_DUMP_STAMPS") && c->pipeline == 1) {
+        // k_encode_tile: [wave][16], wave = 3 * team + channel
+        const size_t waves = (size_t)c->tile_wgs * 12;
+        std::vector<unsigned long long> h(waves * 16);
+        (void)hipMemcpy(h.data(), c->d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        static const char* names[11] = {"head", "samples", "quantise", "walk", "dc+totals", "meet1", "scan+append", "lookback", "meet2", "writeout", "word0"};
+        for (int ch = 0; ch < 3; ++ch) {
+            double sum[11] = {0}, tiles = 0, wall = 0;
+            size_t nw = 0;
+            for (size_t w = ch; w < waves; w += 3) {
+                if (!h[w * 16 + 14]) continue;
+                for (int i = 0; i < 11; ++i) sum[i] += (double)h[w * 16 + i];
+                tiles += (double)h[w * 16 + 14];
+                wall += (double)(h[w * 16 + 15] - h[w * 16 + 13]) * 0.01;
+                ++nw;
+            }
+            fprintf(stderr, "[tstamps] chan %d: %zu waves, %.1f tiles/wave, wall %.1f us/wave | cycles per tile:", ch, nw, tiles / (nw ? nw : 1), wall / (nw ? nw : 1));
+            double tot = 0;
+            for (int i = 0; i < 11; ++i) fprintf(stderr, " %s %.0f", names[i], sum[i] / (tiles ? tiles : 1)), tot += sum[i];
+            fprintf(stderr, " | total %.0f\n", tot / (tiles ? tiles : 1));
+        }
+    }
+    if (c->d_stamps && getenv("MI355_JPEG_DUMP_STAMPS") && c->pipeline == 0) {
         std::vector<unsigned long long> h(4096 * 8);
         (void)hipMemcpy(h.data(), c->d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
         double sum[8] = {0};

@@ -748,8 +748,8 @@ def test_screen_counters_are_exposed(jpeg):
 
 @pytest.mark.parametrize("pipeline", ["tile", "launches"])
 def test_both_pipelines_are_bit_identical(jpeg, monkeypatch, pipeline):
-    """MI355_JPEG_PIPELINE=tile (the default: the single-launch kernel of jpeg_tile_kernels.hip -- three waves per
-    tile, in-kernel look-back scan + merge) and =launches (block-encode kernel + three tail kernels) against the
+    """MI355_JPEG_PIPELINE=tile (the single-launch kernel of jpeg_tile_kernels.hip -- three waves per tile, in-kernel
+    look-back scan + merge) and =launches (the default: block-encode kernel + three tail kernels) against the
     oracle: ragged sizes, one-tile and many-tile frames, batches (several frames per look-back group and several
     groups), high quality (strings longer than their LDS slot, tiles larger than the bit window), the capacity
     error, and the stage probes."""
