@@ -15,7 +15,11 @@
  * fails with MI355_E_NO_DEVICE / a HIP error when no gfx950 device is usable.
  *
  * Threading: a context is single-owner.  One context per GPU per host thread;
- * contexts are independent.
+ * contexts are independent.  The device workspace, the status word and the hand-off
+ * records of a context are per context, not per stream: issue the encode calls of ONE
+ * context in stream order on ONE stream at a time (sync, or order the streams with an
+ * event, before switching to another stream).  Callers that keep several calls in
+ * flight use one context per stream (mi355_jpeg_pool does: one context per worker).
  */
 #ifndef MI355_JPEG_H
 #define MI355_JPEG_H
@@ -157,14 +161,25 @@ int mi355_jpeg_encode_scan(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, 
 /* Device buffers in, device buffers out, asynchronous on `stream` (a
  * hipStream_t, NULL = default stream).  d_bits: device array of n_frames
  * uint64.  Errors detected on the device (capacity, category) are reported by
- * the next mi355_jpeg_sync(). */
+ * the next mi355_jpeg_sync(), and PER FRAME in d_bits: a frame whose scan does not fit
+ * out_stride, or that holds a coefficient without a code, gets d_bits[f] = UINT64_MAX
+ * (its output bytes are undefined); every other frame of the call is complete and valid.
+ *
+ * n_frames: 1 .. 65535, any out_stride >= 8 (a multiple of 4); a batch is never refused for its
+ * size (it is cut into parts internally).  Device memory the library allocates for a call
+ * (kept for later calls, grown on demand): for ONE part of <= ~16 4K frames' worth of pixels,
+ * twice, whatever n_frames -- per frame of a part 8 bytes per unit (units = 8x8 blocks x 3) plus
+ * 2 x min(9/16 x out_stride + 4 x units, 216 x units) + 0.25 MiB of string arena; 12 bytes per
+ * tile (64 blocks) for every frame of the batch.  E.g. 128 4K frames at out_stride = 8 MiB:
+ * 1.4 GB; at out_stride = mi355_jpeg_scan_bound (84 MB): 5.5 GB.  MI355_JPEG_PIPELINE=tile
+ * (strict / standard 4:4:4) needs 40 bytes per tile and nothing else. */
 int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx *ctx, const void *d_rgb, uint32_t W, uint32_t H,
                                   uint32_t n_frames, uint32_t flags, void *d_out,
                                   size_t out_stride, uint64_t *d_bits, void *stream);
 /* Waits for `stream`, then returns the first device-side error of the calls
- * issued since the previous sync (MI355_OK if none).  After an error EVERYTHING issued on this
- * context since the previous sync must be discarded: the outputs of those calls are undefined (frames
- * after the failing one are not written at all). */
+ * issued since the previous sync (MI355_OK if none).  After MI355_E_CAPACITY / MI355_E_CATEGORY the
+ * frames at fault are the ones whose d_bits entry is UINT64_MAX; all other frames of those calls are
+ * good.  After MI355_E_INTERNAL everything issued since the previous sync must be discarded. */
 int mi355_jpeg_sync(mi355_jpeg_ctx *ctx, void *stream);
 
 /* Whole file: build-defined JFIF framing (the reference writes no container,

@@ -32,7 +32,7 @@ inline size_t unit_off_words(const Geom& g) { return (size_t)g.tiles * 192; }
 struct ScreenParams {
     const uint4* afrag;     // [4 row tiles][5 digits][64 lanes] 16 int8: MFMA A fragments of the fixed-point map
     const double* qconst;   // [2 channel types][64 zig-zag positions][4] = {s1, thr1, s2, thr2}
-    const float* qconst_f;  // [2][16 groups of 4 positions][8] = {2^-20/Q x4, first-look threshold x4}
+    const float* qconst_f;  // [2][16 groups of 4 positions][8] = {2^-23/Q x4, first-look threshold x4}
     const double* qd;       // [2][64] quantiser divisors as doubles, natural order
     const uint32_t* qnat_zz; // [2][64] quantiser divisors as integers, ZIG-ZAG order (standard mode's exact decision)
     const uint32_t* lut;    // [4][256] Huffman LUTs (code << 5 | len)
@@ -48,6 +48,7 @@ struct ScreenParams {
     uint32_t stagger;       // k_screen_encode: those workgroups start this many s_sleep(127) (~3.4 us each) late (0: none)
     uint32_t* status;
     uint32_t* tile_bits;    // [frame][tile] bit totals, accumulated with atomics (zero on entry)
+    uint32_t* frame_err;    // [frame] error flags of this launch's frames (bit 0 category, bit 1 arena; zero on entry) or nullptr
     uint32_t* coefs;        // probe output (tiled coefficient layout) or nullptr
     uint8_t* samples;       // probe output (padded YCbCr image, interleaved) or nullptr
     unsigned long long* stamps;  // diagnostic build only (-DMI355_STAMPS): [wave][8] phase cycle sums
@@ -79,8 +80,8 @@ hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t*
 hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams& sp, hipStream_t s);
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,
                         const uint32_t* lut, const uint64_t* tile_off,
-                        uint8_t* out, uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,
-                        hipStream_t s);
+                        uint8_t* out, uint64_t out_stride, const uint64_t* frame_bits /* ~0: the frame is skipped */,
+                        uint32_t lds_words_limit, hipStream_t s);
 
 // auxiliary kernels (jpeg_aux_kernels.hip)
 hipError_t launch_lcg_fill(uint8_t* dst, uint64_t frame_bytes, uint32_t n_frames, uint32_t seed0, hipStream_t s);
@@ -99,7 +100,9 @@ hipError_t launch_unit_sizes(const Geom& g, uint32_t n_frames, const uint32_t* c
 hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, uint32_t* tile_bits,
                             uint64_t* tile_off, uint8_t* out, uint64_t out_stride,
                             uint64_t* frame_bits, uint32_t* status, uint32_t* reset_counters,
-                            bool rearm_tiles, uint64_t* chunk_tot, hipStream_t s);
+                            bool rearm_tiles, uint64_t* chunk_tot,
+                            uint32_t* frame_err /* per-frame flags: a flagged or over-capacity frame gets bits = ~0; re-armed; or nullptr */,
+                            hipStream_t s);
 // Frames above 8192 tiles are scanned by scan_chunks(g) workgroups each (4096 tiles per chunk); their totals need
 // scan_chunks(g) words of scratch per frame (`chunk_tot`; nullptr: one workgroup per frame).
 inline uint32_t scan_chunks(const Geom& g) { return g.tiles > 8192 ? (g.tiles + 4095) / 4096 : 0; }

@@ -190,7 +190,8 @@ template <uint32_t NT>
 __global__ void __launch_bounds__(NT)
     k_tile_scan(Geom g, uint32_t* __restrict__ tile_bits, uint64_t* __restrict__ tile_off,
                 uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ frame_bits,
-                uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters, uint32_t rearm_tiles) {
+                uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters, uint32_t rearm_tiles,
+                uint32_t* __restrict__ frame_err) {
     constexpr uint32_t kPer = 4;  // consecutive tiles per thread and chunk
     __shared__ uint32_t s_wave[NT / 64];
     __builtin_amdgcn_s_setprio(3);  // short, on the stream's critical path, resident next to encode kernels
@@ -242,8 +243,16 @@ __global__ void __launch_bounds__(NT)
     }
     if (tid == 0) {
         to[g.tiles] = carry;
-        frame_bits[frame] = carry;
-        if (((carry + 31) >> 5) * 4 > out_stride) atomicOr(status, 2u);  // MI355_E_CAPACITY
+        const bool over = ((carry + 31) >> 5) * 4 > out_stride;
+        if (over) atomicOr(status, 2u);  // MI355_E_CAPACITY
+        // Per-frame verdict: a frame that does not fit, or that a kernel flagged (a size without a code, arena exhausted),
+        // gets the bit count ~0 and is skipped by the merge; the other frames of the call are complete and valid.
+        bool flagged = false;
+        if (frame_err) {
+            flagged = frame_err[frame] != 0;
+            frame_err[frame] = 0;  // re-armed for the next call
+        }
+        frame_bits[frame] = (over || flagged) ? ~0ull : carry;
         // the screened pipeline's arena counter is consumed by now: re-arm it
         if (reset_counters && frame == 0) reset_counters[0] = 0;
     }
@@ -298,7 +307,7 @@ __global__ void __launch_bounds__(1024)
 __global__ void __launch_bounds__(1024)
     k_tile_fix(Geom g, uint64_t* __restrict__ tile_off, const uint64_t* __restrict__ chunk_tot, uint32_t chunks,
                uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ frame_bits,
-               uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters) {
+               uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters, uint32_t* __restrict__ frame_err) {
     __builtin_amdgcn_s_setprio(3);
     const uint32_t tid = threadIdx.x;
     const uint32_t c = blockIdx.x, frame = blockIdx.y;
@@ -321,8 +330,14 @@ __global__ void __launch_bounds__(1024)
     if (c + 1 == chunks && tid == 0) {
         const uint64_t total = before + ct[c];
         to[g.tiles] = total;
-        frame_bits[frame] = total;
-        if (((total + 31) >> 5) * 4 > out_stride) atomicOr(status, 2u);  // MI355_E_CAPACITY
+        const bool over = ((total + 31) >> 5) * 4 > out_stride;
+        if (over) atomicOr(status, 2u);  // MI355_E_CAPACITY
+        bool flagged = false;
+        if (frame_err) {  // see k_tile_scan
+            flagged = frame_err[frame] != 0;
+            frame_err[frame] = 0;
+        }
+        frame_bits[frame] = (over || flagged) ? ~0ull : total;
         if (reset_counters && frame == 0) reset_counters[0] = 0;
     }
 }
@@ -482,19 +497,19 @@ hipError_t launch_unit_sizes(const Geom& g, uint32_t n_frames, const uint32_t* c
 hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, uint32_t* tile_bits,
                             uint64_t* tile_off, uint8_t* out, uint64_t out_stride,
                             uint64_t* frame_bits, uint32_t* status, uint32_t* reset_counters,
-                            bool rearm_tiles, uint64_t* chunk_tot, hipStream_t s) {
+                            bool rearm_tiles, uint64_t* chunk_tot, uint32_t* frame_err, hipStream_t s) {
     if (g.tiles <= 8192) {
         hipLaunchKernelGGL(k_tile_scan<256>, dim3(n_frames), dim3(256), 0, s, g, tile_bits, tile_off, out,
-                           out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u);
+                           out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u, frame_err);
     } else if (chunk_tot) {  // several workgroups per frame, two launches
         const uint32_t chunks = scan_chunks(g);
         hipLaunchKernelGGL(k_tile_chunks, dim3(chunks, n_frames), dim3(1024), 0, s, g, tile_bits, tile_off, chunk_tot,
                            chunks, rearm_tiles ? 1u : 0u);
         hipLaunchKernelGGL(k_tile_fix, dim3(chunks, n_frames), dim3(1024), 0, s, g, tile_off, chunk_tot, chunks, out,
-                           out_stride, frame_bits, status, reset_counters);
+                           out_stride, frame_bits, status, reset_counters, frame_err);
     } else {
         hipLaunchKernelGGL(k_tile_scan<1024>, dim3(n_frames), dim3(1024), 0, s, g, tile_bits, tile_off, out,
-                           out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u);
+                           out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u, frame_err);
     }
     return hipGetLastError();
 }

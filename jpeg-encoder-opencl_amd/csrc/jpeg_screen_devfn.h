@@ -1,7 +1,8 @@
 // Device-side building blocks of the screened (integer-MFMA) pipeline, shared by its two kernel
-// files: jpeg_fused_kernels.hip (the single-launch pipeline: block encode + in-kernel scan and merge)
-// and jpeg_screen_kernels.hip (the four-launch pipeline, still used for 4:2:0 standard mode and as the
-// A/B reference).  See jpeg_screen_kernels.hip's header comment for why the screen is bit-exact.
+// files: jpeg_screen_kernels.hip (the four-launch pipeline: the library's DEFAULT, and the only one for
+// 4:2:0 standard mode) and jpeg_tile_kernels.hip (the single-launch pipeline: three waves per tile,
+// in-kernel scan and merge; opt-in with MI355_JPEG_PIPELINE=tile).  See jpeg_screen_kernels.hip's
+// header comment for why the screen is bit-exact.
 #pragma once
 #include "jpeg_devfn.h"
 #include "jpeg_screen_tables.h"  // kScreenLimbs, kScreenFracBits (the tables themselves are uploaded by the host)

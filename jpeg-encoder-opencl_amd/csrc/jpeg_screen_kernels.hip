@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256, 2)
     __shared__ uint32_t s_tbuf_all[kEncWaves][kRowWords];          // zig-zag rows, int16 [position][unit] (jpeg_screen_devfn.h)
     __shared__ alignas(16) uint32_t s_slot_all[kEncWaves][(kSlotRows + 1) * 64];  // AC strings [word][lane] + dump row
     __shared__ uint32_t s_mask_all[kEncWaves][2][64];              // non-zero masks (lo, hi)
-    __shared__ float s_qf[2][16][8];    // per group of 4 positions: 2^-20/Q x4, first-look thresholds x4
+    __shared__ float s_qf[2][16][8];    // per group of 4 positions: 2^-23/Q x4 (first look: top three digits), its thresholds x4
     __shared__ uint32_t s_act[2][256];  // (run,size) AC tables
     __shared__ uint32_t s_lut2[2][kLut2Words];  // (value,run) symbol tables
     __shared__ uint32_t s_dc[2][16];      // DC tables
@@ -390,7 +390,10 @@ __global__ void __launch_bounds__(256, 2)
         uint32_t nw = pkr.words();
         STAMP(2);
         const bool oversize = nw > kSlotRows;
-        if (!ok && active) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
+        if (!ok && active) {  // MI355_E_CATEGORY
+            atomicOr(sp.status, 1u);
+            if (sp.frame_err) atomicOr(&sp.frame_err[frame], 1u);
+        }
         if (!active) nw = 0;
 
         // Total bits of the unit = DC symbol + AC string.  The DC difference needs the previous
@@ -402,7 +405,10 @@ __global__ void __launch_bounds__(256, 2)
             uint32_t ubits = aclen;
             auto count = [&](uint32_t, uint32_t len) { ubits += len; };
             const bool dc_ok = lane == 0 || put_dc(dc - pred, s_dc[ct], count);
-            if (!dc_ok && active) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
+            if (!dc_ok && active) {  // MI355_E_CATEGORY
+                atomicOr(sp.status, 1u);
+                if (sp.frame_err) atomicOr(&sp.frame_err[frame], 1u);
+            }
             if (!active) ubits = 0;
             ubits = wave_sum(ubits);
             if (lane == 0 && ubits) atomicAdd(&sp.tile_bits[(size_t)frame * g.tiles + tile], ubits);
@@ -416,7 +422,10 @@ __global__ void __launch_bounds__(256, 2)
         const uint32_t off = base + incl - need;
         const bool fits = base != 0xFFFFFFFFu;
         if (!fits) {
-            if (lane == 0) atomicOr(sp.status, 2u);  // MI355_E_CAPACITY
+            if (lane == 0) {  // MI355_E_CAPACITY (strings beyond 9/4 of the output capacity: the output could not hold them either)
+                atomicOr(sp.status, 2u);
+                if (sp.frame_err) atomicOr(&sp.frame_err[frame], 2u);
+            }
         } else {
 #ifdef MI355_DIAG_NOARENA  // timing experiment only (wrong output): no AC strings written
             const uint32_t ncopy = 0u;
@@ -487,7 +496,10 @@ __global__ void __launch_bounds__(64)
         const int dc = meta_dc(sp.meta[u0].y);
         uint32_t len = 0;
         auto count = [&](uint32_t, uint32_t l) { len += l; };
-        if (!put_dc(dc - pred, s_dcf[luma ? 0 : 1], count)) atomicOr(sp.status, 1u);  // MI355_E_CATEGORY
+        if (!put_dc(dc - pred, s_dcf[luma ? 0 : 1], count)) {  // MI355_E_CATEGORY
+            atomicOr(sp.status, 1u);
+            if (sp.frame_err) atomicOr(&sp.frame_err[ft / g.tiles], 1u);
+        }
         atomicAdd(&sp.tile_bits[ft], len);
     }
 }
@@ -515,7 +527,7 @@ template <bool S420>
 __global__ void __launch_bounds__(S420 ? 384 : 192)
     k_merge(Geom g, const uint2* __restrict__ meta, const uint32_t* __restrict__ arena,
             const uint32_t* __restrict__ lut, const uint64_t* __restrict__ tile_off,
-            uint8_t* __restrict__ out, uint64_t out_stride, const uint32_t* __restrict__ status,
+            uint8_t* __restrict__ out, uint64_t out_stride, const uint64_t* __restrict__ frame_bits,
             uint32_t lds_words_limit) {
     constexpr uint32_t NT = S420 ? 384 : 192, UPB = S420 ? 6 : 3;  // threads, units per scan step (block / MCU)
     __builtin_amdgcn_s_setprio(3);  // see k_dc_heads
@@ -527,12 +539,9 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
     __shared__ uint32_t s_words[kWindow];
     const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
     const uint32_t tile = blockIdx.x, frame = blockIdx.y;
-    // one read per workgroup, behind a barrier: waves that saw different values of a status word another
-    // part's kernel is setting right now would otherwise diverge around the barriers below
-    __shared__ uint32_t s_status;
-    if (tid == 0) s_status = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_status) return;
+    // a frame with an error (k_tile_scan wrote its bit count as ~0: over capacity, a size without a code, arena
+    // exhausted) is skipped as a whole; the other frames of the call are written in full
+    if (frame_bits[frame] == ~0ull) return;
     if (lds_words_limit > kWindow) lds_words_limit = kWindow;
     const size_t ft0 = (size_t)frame * g.tiles;
     const uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
@@ -698,15 +707,15 @@ hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams&
 }
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,
                         const uint32_t* lut, const uint64_t* tile_off,
-                        uint8_t* out, uint64_t out_stride, const uint32_t* status, uint32_t lds_words_limit,
+                        uint8_t* out, uint64_t out_stride, const uint64_t* frame_bits, uint32_t lds_words_limit,
                         hipStream_t s) {
     if (lds_words_limit > kEmitLdsWords) lds_words_limit = kEmitLdsWords;
     if (is420(g))
         hipLaunchKernelGGL(k_merge<true>, dim3(g.tiles, n_frames), dim3(384), 0, s, g, meta, arena, lut,
-                           tile_off, out, out_stride, status, lds_words_limit);
+                           tile_off, out, out_stride, frame_bits, lds_words_limit);
     else
         hipLaunchKernelGGL(k_merge<false>, dim3(g.tiles, n_frames), dim3(192), 0, s, g, meta, arena, lut,
-                           tile_off, out, out_stride, status, lds_words_limit);
+                           tile_off, out, out_stride, frame_bits, lds_words_limit);
     return hipGetLastError();
 }
 

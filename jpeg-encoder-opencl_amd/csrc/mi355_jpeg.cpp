@@ -116,8 +116,10 @@ struct mi355_jpeg_ctx {
     // batches are encoded as two halves: the tail kernels of the first half run on `side` under the
     // block-encode kernel of the second half
     hipStream_t side = nullptr;
-    hipEvent_t ev_half = nullptr, ev_side = nullptr;
-    uint32_t batch_parts = 8;  // MI355_JPEG_BATCH_PARTS: upper limit of the parts of a batch (1 = off, at most 8)
+    hipEvent_t ev_half = nullptr, ev_side = nullptr, ev_set[2] = {nullptr, nullptr};
+    uint32_t batch_parts = 0xFFFFu;  // MI355_JPEG_BATCH_PARTS (1..8): upper limit of the parts of a batch (1 = off)
+    uint32_t* d_frame_err = nullptr;  // [frames] per-frame error flags of the four-launch pipeline (zero between calls)
+    size_t frame_err_cap = 0;
     uint32_t qlum[64], qchrom[64];
     mi355_huff_table huff[4];
     mi355_huff_table huff_std[4];  // standard mode (MI355_F_STANDARD): Annex K proper unless the caller set a table
@@ -147,7 +149,7 @@ struct mi355_jpeg_ctx {
     double* d_qconst = nullptr;     // [2][64][4] accept thresholds for the current tables
     float* d_qconst_f = nullptr;    // [2 maps][2][16][8] fp32 first-look scale factors and thresholds
     uint32_t* d_lut2 = nullptr;     // [2 modes][2][66][16] whole AC symbols for |value| <= 31
-    uint32_t* d_counters = nullptr; // [0..7] arena overflow-pool words of the parts of a batch
+    uint32_t* d_counters = nullptr; // [0..1] arena overflow-pool words of the two workspace sets ([2..7] unused)
     unsigned long long* d_stats = nullptr;  // [0] second looks, [1] exact units (mi355_jpeg_screen_stats)
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
     uint8_t* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // scratch of the stage-by-stage entry points
@@ -423,6 +425,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.stats = c->d_stats;
     sp.status = c->d_status;
     sp.tile_bits = c->d_tile_bits;
+    sp.frame_err = nullptr;
     sp.coefs = coefs;
     sp.samples = nullptr;
     sp.stamps = nullptr;
@@ -485,7 +488,7 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
     // invariant: d_tile_bits is all zero between API calls (the screened pipeline accumulates into it)
     HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
                              c->d_status, nullptr, true,
-                             scan_chunks(g) ? c->d_tile_off + ((size_t)g.tiles + 1) * n_frames : nullptr, s));
+                             scan_chunks(g) ? c->d_tile_off + ((size_t)g.tiles + 1) * n_frames : nullptr, nullptr, s));
     record(c, 3, s);
     HIP_TRY(launch_emit(g, n_frames, c->d_coefs, c->d_lut, c->d_unit_off, c->d_tile_off, d_out,
                         out_stride, c->d_status, c->emit_lds_words, s));
@@ -493,22 +496,21 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
     return MI355_OK;
 }
 
-// One part of a batch: frames [f0, f0 + nf) with their slices of the workspace; `arena0` = first arena
-// word of this part, `counter` = its overflow-pool pointer.
-constexpr uint32_t kMaxParts = 8;
+// One part of a batch: frames [f0, f0 + nf).  Parts alternate between two sets of {meta, arena, overflow counter}:
+// part i + 2 reuses the set of part i once that part's tail kernels are done.
 struct BatchPart {
     uint32_t f0, nf;
     ArenaPlan plan;
-    size_t arena0;
-    uint32_t counter;
+    uint32_t set;  // 0 / 1
 };
 
-ScreenParams part_params(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p) {
+ScreenParams part_params(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p, size_t set_meta, size_t set_arena) {
     ScreenParams sp = screen_params(c, g, p.nf, p.plan, nullptr);
-    sp.meta = c->d_meta + (size_t)p.f0 * g.tiles * g.passes * 64;
-    sp.arena = c->d_arena + p.arena0;
-    sp.counters = c->d_counters + p.counter;
+    sp.meta = c->d_meta + (size_t)p.set * set_meta;
+    sp.arena = c->d_arena + (size_t)p.set * set_arena;
+    sp.counters = c->d_counters + p.set;
     sp.tile_bits = c->d_tile_bits + (size_t)p.f0 * g.tiles;
+    sp.frame_err = c->d_frame_err + p.f0;
     return sp;
 }
 
@@ -519,65 +521,89 @@ int launch_tails(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p, const Scr
     HIP_TRY(launch_tile_scan(g, p.nf, sp.tile_bits, c->d_tile_off + (size_t)p.f0 * (g.tiles + 1),
                              d_out + (size_t)p.f0 * out_stride, out_stride, d_bits + p.f0, c->d_status, sp.counters,
                              true, scan_chunks(g) ? c->d_tile_off + ((size_t)g.tiles + 1) * batch_frames + (size_t)p.f0 * scan_chunks(g) : nullptr,
-                             s));
+                             sp.frame_err, s));
     if (rec) record(c, 3, s);
     HIP_TRY(launch_merge(g, p.nf, sp.meta, sp.arena, sp.lut, c->d_tile_off + (size_t)p.f0 * (g.tiles + 1),
-                         d_out + (size_t)p.f0 * out_stride, out_stride, c->d_status, c->emit_lds_words, s));
+                         d_out + (size_t)p.f0 * out_stride, out_stride, d_bits + p.f0, c->emit_lds_words, s));
     if (rec) record(c, 4, s);
     return MI355_OK;
 }
 
 // Screened pipeline: k_screen_encode -> k_dc_heads -> k_tile_scan -> k_merge.
 // Event slots: [0,1] fused block encode (transform_ms), [1,2] DC heads (size_ms), [2,3] scan, [3,4] merge (emit_ms).
-// Batches of four or more frames go in parts: the tail kernels of a part run on a side stream under the
-// block-encode kernel of the next part (they fit next to its resident workgroups); with
-// per-stage profiling on, one part, so that the stage times stay meaningful.
+// Batches of four or more frames go in parts of ~128 Mpixel (16 4K frames: ~0.5 ms of block encode; the kernel's time
+// per frame is best between 12 and 20 4K frames per launch): the tail kernels of a part run on a side
+// stream under the block-encode kernel of the next part (they fit next to its resident workgroups);
+// with per-stage profiling on, one part, so that the stage times stay meaningful.
+//
+// Workspace (device memory the library allocates; grown on demand, never shrunk): TWO sets of {per-unit metadata,
+// string arena}, each sized for ONE part, whatever the batch -- parts alternate between them.  Per frame of a part:
+// 8 bytes per unit of metadata, and an arena of 2 x min(9/16 x out_stride + 4 x units, 216 x units) + 0.25 MiB bytes
+// (units = blocks x 3; 216 bytes = the longest possible AC string; the factor 2 = every wave's private region + an
+// overflow pool that could hold everything).  A part's arena offsets are 32-bit words relative to the part, so the
+// size of a batch is not limited by them; parts shrink where a frame is so large that 16 of them would not fit.
 int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t* d_rgb, uint8_t* d_out,
                  size_t out_stride, uint64_t* d_bits, hipStream_t s) {
-    // parts: at least two frames and ~64 Mpixel (~0.4 ms of block encode) each -- every part pays the ramp and
-    // tail of one more launch -- at most batch_parts (8)
+    // AC strings are word aligned per unit (<= bits/32 + 1 words); strings longer than the LDS slot (24 words) get a
+    // full 54-word run, i.e. at most 54/24 of their own size.  A frame whose strings exceed 9/4 of the output capacity
+    // (+ one word per unit) cannot fit the output either; and no frame needs more than 54 words per unit.
+    const size_t by_capacity = out_stride / 4 * 9 / 4 + unit_count(g) + 64, by_units = unit_count(g) * 54 + 64;
+    const size_t frame_words = by_capacity < by_units ? by_capacity : by_units;
     uint32_t nparts = 1;
     if (n_frames >= 4 && c->profiling != 1) {
         const uint64_t px = (uint64_t)n_frames * g.W * g.H;
-        nparts = (uint32_t)(px >> 26);
+        nparts = (uint32_t)((px + (1ull << 26)) >> 27);
         if (nparts > n_frames / 2) nparts = n_frames / 2;
         if (nparts > c->batch_parts) nparts = c->batch_parts;
         if (nparts < 1) nparts = 1;
     }
-    BatchPart part[kMaxParts];
-    size_t arena_words = 0;
-    for (uint32_t i = 0, f = 0; i < nparts; ++i) {
-        part[i].f0 = f;
-        part[i].nf = (uint32_t)(((uint64_t)n_frames * (i + 1)) / nparts) - f;
-        f += part[i].nf;
-        // AC strings are word aligned per unit (<= bits/32 + 1 words); strings longer than the LDS
-        // slot (24 words) get a full 54-word run, i.e. at most 54/24 of their own size
-        part[i].plan = plan_arena(c, g, part[i].nf, (size_t)part[i].nf * (out_stride / 4 * 9 / 4 + unit_count(g) + 64));
-        part[i].arena0 = arena_words;
-        part[i].counter = i;
-        arena_words += part[i].plan.total_words;
-        if (arena_words > 0xFFFFFFFFull) return MI355_E_ARG;  // 32-bit word offsets: split the batch
+    // 32-bit word offsets inside a part: 2 x frame_words x frames + slack must stay below 2^32
+    {
+        const uint64_t max_pf = frame_words * 2 + (1u << 16) < (1ull << 32) ? ((1ull << 32) - (1ull << 24)) / (frame_words * 2 + (1u << 16)) : 0;
+        if (max_pf == 0) return MI355_E_ARG;  // one frame alone beyond 2^32 arena words (> 39 M blocks at the capacity given)
+        const uint32_t need_parts = (uint32_t)((n_frames + max_pf - 1) / max_pf);
+        if (nparts < need_parts) nparts = need_parts;
     }
+    uint32_t max_nf = 0;
+    for (uint32_t i = 0; i < nparts; ++i) {
+        const uint32_t nf = (uint32_t)(((uint64_t)n_frames * (i + 1)) / nparts) - (uint32_t)(((uint64_t)n_frames * i) / nparts);
+        max_nf = nf > max_nf ? nf : max_nf;
+    }
+    const ArenaPlan big = plan_arena(c, g, max_nf, (size_t)max_nf * frame_words);
+    const size_t set_arena = (big.total_words + 63) & ~(size_t)63;
+    const size_t set_meta = (size_t)g.tiles * g.passes * 64 * max_nf;
+    const uint32_t nsets = nparts > 1 ? 2 : 1;
+    if (set_arena > 0xFFFFFFFFull) return MI355_E_ARG;  // (cannot happen: parts were sized for it)
     int e;
-    if ((e = ensure_screen_workspace(c, g, n_frames, arena_words))) return e;
+    if ((e = ensure(c->d_meta, c->meta_cap, set_meta * nsets))) return e;
+    if ((e = ensure(c->d_arena, c->arena_cap, set_arena * nsets))) return e;
+    if ((e = ensure(c->d_frame_err, c->frame_err_cap, (size_t)n_frames, true))) return e;
     if (nparts > 1 && !c->side) {
         HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_set[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_set[1], hipEventDisableTiming));
     }
     record(c, 0, s);
     c->last_launches = nparts;
     for (uint32_t i = 0; i < nparts; ++i) {
-        const ScreenParams sp = part_params(c, g, part[i]);
-        HIP_TRY(launch_screen_encode(g, part[i].nf, d_rgb + (size_t)part[i].f0 * g.frame_stride, sp, false,
-                                     c->screen_waves, s));
+        BatchPart part;
+        part.f0 = (uint32_t)(((uint64_t)n_frames * i) / nparts);
+        part.nf = (uint32_t)(((uint64_t)n_frames * (i + 1)) / nparts) - part.f0;
+        part.plan = plan_arena(c, g, part.nf, (size_t)part.nf * frame_words);
+        part.set = i & 1u;
+        const ScreenParams sp = part_params(c, g, part, set_meta, set_arena);
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, c->ev_set[part.set], 0));  // the tails of part i - 2 are done with this set
+        HIP_TRY(launch_screen_encode(g, part.nf, d_rgb + (size_t)part.f0 * g.frame_stride, sp, false, c->screen_waves, s));
         if (i + 1 == nparts) {  // the last part's tails stay on the caller's stream
             record(c, 1, s);
-            if ((e = launch_tails(c, g, part[i], sp, d_out, out_stride, d_bits, s, nparts == 1, n_frames))) return e;
+            if ((e = launch_tails(c, g, part, sp, d_out, out_stride, d_bits, s, nparts == 1, n_frames))) return e;
         } else {  // tails on the side stream, under the next part's block encode
             HIP_TRY(hipEventRecord(c->ev_half, s));
             HIP_TRY(hipStreamWaitEvent(c->side, c->ev_half, 0));
-            if ((e = launch_tails(c, g, part[i], sp, d_out, out_stride, d_bits, c->side, false, n_frames))) return e;
+            if ((e = launch_tails(c, g, part, sp, d_out, out_stride, d_bits, c->side, false, n_frames))) return e;
+            HIP_TRY(hipEventRecord(c->ev_set[part.set], c->side));
         }
     }
     if (nparts > 1) {
@@ -662,7 +688,7 @@ struct Knobs {
     int transform_mode = 2;
     uint32_t emit_lds_words = 4096;
     double tau_scale = 1.0;
-    uint32_t batch_parts = 8;
+    uint32_t batch_parts = 0xFFFFu;
     int pipeline = 0;
     uint32_t screen_waves = 0;  // 0: the device's default
 };
@@ -797,10 +823,12 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_half) (void)hipEventDestroy(c->ev_half);
     if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+    for (hipEvent_t ev : c->ev_set)
+        if (ev) (void)hipEventDestroy(ev);
     void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
                     c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
                     c->d_counters, c->d_meta,     c->d_arena,  c->d_lut2,     c->d_qconst_f,
-                    c->d_stuff_counts, c->d_stuff_offs, c->d_qzz, c->d_stats, c->d_rec, c->d_ticket, c->d_ovf};
+                    c->d_stuff_counts, c->d_stuff_offs, c->d_qzz, c->d_stats, c->d_rec, c->d_ticket, c->d_ovf, c->d_frame_err};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : c->d_stage)
@@ -1552,10 +1580,13 @@ struct Stage {
         return e ? nullptr : c->d_stage[which];
     }
     void up(void* d, const void* h, size_t n) {
-        if (!e && hipMemcpy(d, h, n, hipMemcpyHostToDevice) != hipSuccess) e = MI355_E_HIP - (int)hipGetLastError();
+        if (!e) e = hip_err(hipMemcpy(d, h, n, hipMemcpyHostToDevice));
     }
     void down(void* h, const void* d, size_t n) {
-        if (!e && hipMemcpy(h, d, n, hipMemcpyDeviceToHost) != hipSuccess) e = MI355_E_HIP - (int)hipGetLastError();
+        if (!e) e = hip_err(hipMemcpy(h, d, n, hipMemcpyDeviceToHost));
+    }
+    void zero(void* d, size_t n) {
+        if (!e) e = hip_err(hipMemset(d, 0, n));
     }
     void run(hipError_t le) {
         if (!e && le != hipSuccess) e = MI355_E_HIP - (int)le;
@@ -1713,19 +1744,23 @@ int mi355_jpeg_stage_huffman(mi355_jpeg_ctx* c, const int32_t* zigzag, const int
     const size_t out_words = (cap + 3) / 4;
     int* dz = (int*)st.buf(0, rows * 64 * sizeof(int));
     int* dp = (int*)st.buf(1, rows * 128 * sizeof(int));
-    // counts | unit bits | in-chunk offsets | chunk sums (u64) | total (u64), then the output words
+    // counts | unit bits | in-chunk offsets | chunk sums (u64) | total (u64) | status word of THIS call, then the output
+    // words.  The call has a status word of its own: the context-wide one belongs to the asynchronous encode calls (a
+    // pending error of one of them must stay there for the caller's next mi355_jpeg_sync, not surface here).
     const size_t off_ub = rows * 4, off_ic = off_ub + rows * 4, off_cs = (off_ic + rows * 4 + 7) & ~(size_t)7;
-    const size_t off_tot = off_cs + chunks * 8, off_out = off_tot + 8;
+    const size_t off_tot = off_cs + chunks * 8, off_st = off_tot + 8, off_out = off_st + 8;
     uint8_t* dm = (uint8_t*)st.buf(2, off_out + out_words * 4);
     st.up(dz, zigzag, rows * 64 * sizeof(int));
     st.up(dp, pairs, rows * 128 * sizeof(int));
     st.up(dm, counts, rows * 4);
-    if (!st.e && hipMemset(dm + off_out, 0, out_words * 4) != hipSuccess) st.e = MI355_E_ALLOC;
+    st.zero(dm + off_st, 8 + out_words * 4);
     if (!st.e)
         st.run(launch_stage_huffman(dz, dp, (const uint32_t*)dm, N, c->d_lut, (uint32_t*)(dm + off_ub), (uint32_t*)(dm + off_ic),
                                     (uint64_t*)(dm + off_cs), (uint64_t*)(dm + off_tot), (uint32_t*)(dm + off_out),
-                                    (uint64_t)out_words * 32, c->d_status, nullptr));
-    if (!st.e) st.e = mi355_jpeg_sync(c, nullptr);
+                                    (uint64_t)out_words * 32, (uint32_t*)(dm + off_st), nullptr));
+    uint32_t stw = 0;
+    st.down(&stw, dm + off_st, sizeof stw);  // (the copy waits for the null stream's kernels)
+    if (!st.e) st.e = status_to_error(stw);
     st.down(bits, dm + off_tot, sizeof(uint64_t));
     if (st.e) return st.e;
     const size_t nb = (size_t)((*bits + 7) / 8);
@@ -1745,7 +1780,10 @@ int mi355_jpeg_last_call_launches(mi355_jpeg_ctx* c, uint32_t* n) {
 int mi355_jpeg_screen_stats(mi355_jpeg_ctx* c, void* stream, mi355_jpeg_screen_counts* out, int reset) {
     if (!c || !out) return MI355_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    (void)stream;
+    // every stream of the device, the library's side stream included: kernels still running anywhere would keep adding
+    // to the counters while they are read or reset
+    HIP_TRY(hipDeviceSynchronize());
     unsigned long long h[2] = {0, 0};
     HIP_TRY(hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
     out->second_looks = h[0];

@@ -888,3 +888,107 @@ def test_config4_per_gpu_share_1024_4k_frames_through_the_pool(jpeg):
         assert int(d_bits[0]) == int(nb[f]) and torch.equal(d_out[:k].cpu(), h_out[f, :k]), f
     print("pool: %d x 4K in %.3f s = %.1f Gpixel/s incl. PCIe" % (n, secs.value, n * W * H / secs.value / 1e9))
     e2.close()
+
+
+@pytest.mark.parametrize("pipeline", ["launches", "tile"])
+def test_per_frame_error_reporting(jpeg, monkeypatch, pipeline):
+    """one frame of a batch does not fit its output slot.  mi355_jpeg_sync reports
+    MI355_E_CAPACITY, that frame's bit count is UINT64_MAX, and the other seven frames are complete and equal
+    to the oracle (before: everything issued since the last sync was undefined).  Then a coefficient without a
+    code in one frame (MI355_E_CATEGORY): same contract."""
+    import torch
+    monkeypatch.setenv("MI355_JPEG_PIPELINE", pipeline)
+    e2 = jpeg.Encoder(0)
+    ql, qc = set_quality(e2, 50)
+    W, H, n = 320, 200, 8
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames = np.stack([np.stack([120 + f + (xx // 40), 125 + (yy // 50) + f, 128 + 0 * xx], -1).astype(np.uint8) for f in range(n)])
+    frames[5] = ol.lcg_frame(W, H, 99)  # noise: more than ten times the bits of the near-flat frames
+    orc = [ol.oracle_encode(frames[f], ql, qc, True) for f in range(n)]
+    small = max(o.n_bits for i, o in enumerate(orc) if i != 5)
+    assert orc[5].n_bits > 2 * small
+    cap = ((small + 7) // 8 + 64 + 3) & ~3
+    dev = torch.device("cuda", 0)
+    d_rgb = torch.from_numpy(frames).to(dev)
+    d_out = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
+    d_bits = torch.zeros(n, dtype=torch.int64, device=dev)
+    e2.encode_scan_device(d_rgb.data_ptr(), W, H, n, d_out.data_ptr(), cap, d_bits.data_ptr())
+    with pytest.raises(jpeg.JpegError) as ei:
+        e2.sync()
+    assert ei.value.status == jpeg.E_CAPACITY
+    bits = d_bits.cpu().numpy().astype(np.uint64)
+    out = d_out.cpu().numpy()
+    assert bits[5] == np.uint64(0xFFFFFFFFFFFFFFFF)
+    for f in range(n):
+        if f == 5:
+            continue
+        assert int(bits[f]) == orc[f].n_bits, f
+        assert np.array_equal(out[f, :(orc[f].n_bits + 7) // 8], orc[f].bits), f
+    # the context is usable again, and the same batch with room for everything is clean
+    cap2 = (orc[5].n_bits + 7) // 8 + 64 & ~3
+    d_out = torch.zeros((n, cap2), dtype=torch.uint8, device=dev)
+    e2.encode_scan_device(d_rgb.data_ptr(), W, H, n, d_out.data_ptr(), cap2, d_bits.data_ptr())
+    e2.sync()
+    assert [int(b) for b in d_bits.cpu().numpy()] == [o.n_bits for o in orc]
+    # a coefficient without a code in ONE frame: quality 100, an AC-luma table without its size-10 entries (a caller's
+    # table may have holes), and one block in frame 2 whose transform reaches +-902 (the others stay below 256)
+    ql, qc = set_quality(e2, 100)
+    fr2 = np.stack([np.stack([xx * 100 // W + yy * 100 // H + f, 50 + yy * 80 // H + f, 200 - xx * 90 // W], -1).astype(np.uint8)
+                    for f in range(n)])
+    fr2[2, :4, :8] = 255
+    fr2[2, 4:8, :8] = 0
+    ok = [ol.oracle_encode(fr2[f], ql, qc, True, ol.KEEP_ZIGZAG) for f in range(n)]
+    Nb = (W // 8) * (H // 8)
+    assert 512 <= np.abs(ok[2].zigzag[:Nb, 1:]).max() < 1024
+    assert all(np.abs(ok[f].zigzag[:Nb, 1:]).max() < 512 for f in range(n) if f != 2)
+    code, length = e2.get_huffman(2)
+    length = length.copy()
+    length[[(r << 4) | 10 for r in range(16)]] = 0
+    e2.set_huffman(2, code, length)
+    cap3 = (max(o.n_bits for o in ok) + 7) // 8 + 4096 & ~3
+    d_rgb = torch.from_numpy(fr2).to(dev)
+    d_out = torch.zeros((n, cap3), dtype=torch.uint8, device=dev)
+    e2.encode_scan_device(d_rgb.data_ptr(), W, H, n, d_out.data_ptr(), cap3, d_bits.data_ptr())
+    with pytest.raises(jpeg.JpegError) as ei:
+        e2.sync()
+    assert ei.value.status == jpeg.E_CATEGORY
+    bits = d_bits.cpu().numpy().astype(np.uint64)
+    out = d_out.cpu().numpy()
+    assert bits[2] == np.uint64(0xFFFFFFFFFFFFFFFF)
+    for f in range(n):
+        if f != 2:
+            assert int(bits[f]) == ok[f].n_bits and np.array_equal(out[f, :(ok[f].n_bits + 7) // 8], ok[f].bits), f
+    e2.close()
+
+
+def test_batch_at_worst_case_capacity_is_accepted(jpeg, enc):
+    """128 4K frames in ONE call with out_stride = mi355_jpeg_scan_bound (84 MB per frame, what
+    the header recommends) used to be refused with MI355_E_ARG (the workspace was sized from the caller's capacity
+    and addressed with 32-bit offsets across the whole batch); and 512 frames at 8 MiB likewise.  Both succeed now,
+    sampled frames equal the reference build's goldens."""
+    import torch
+    W, H = 3840, 2160
+    gold = _golden(W, H, 50)
+    set_quality(enc, 50)
+    dev = torch.device("cuda", 0)
+    for n, cap in ((128, (jpeg.scan_bound(W, H) + 3) & ~3), (512, 8 << 20)):
+        d_rgb = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+        enc.synth_lcg_device(d_rgb.data_ptr(), W * H * 3, n, 1)
+        d_out = torch.empty((n, cap), dtype=torch.uint8, device=dev)
+        d_bits = torch.zeros(n, dtype=torch.int64, device=dev)
+        enc.encode_scan_device(d_rgb.data_ptr(), W, H, n, d_out.data_ptr(), cap, d_bits.data_ptr())
+        enc.sync()
+        bits = d_bits.cpu().numpy()
+        assert (bits > 0).all() and (bits < 8 * (6 << 20)).all()
+        checked = 0
+        for f in range(n):
+            g = gold.get(1 + f)
+            if g is None:
+                continue
+            assert int(bits[f]) == g[0], (n, f)
+            assert ascii_sha(d_out[f, :(g[0] + 7) // 8].cpu().numpy(), g[0]) == g[1], (n, f)
+            checked += 1
+        assert checked >= 4
+        assert enc.last_call_parts() >= n // 20
+        del d_rgb, d_out, d_bits
+        torch.cuda.empty_cache()
