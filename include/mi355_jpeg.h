@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MI355_JPEG_ABI_VERSION 2
+#define MI355_JPEG_ABI_VERSION 3
 
 typedef struct mi355_jpeg_ctx mi355_jpeg_ctx;
 
@@ -166,13 +166,15 @@ int mi355_jpeg_encode_scan(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, 
  * (its output bytes are undefined); every other frame of the call is complete and valid.
  *
  * n_frames: 1 .. 65535, any out_stride >= 8 (a multiple of 4); a batch is never refused for its
- * size (it is cut into parts internally).  Device memory the library allocates for a call
- * (kept for later calls, grown on demand): for ONE part of <= ~16 4K frames' worth of pixels,
- * twice, whatever n_frames -- per frame of a part 8 bytes per unit (units = 8x8 blocks x 3) plus
- * 2 x min(9/16 x out_stride + 4 x units, 216 x units) + 0.25 MiB of string arena; 12 bytes per
- * tile (64 blocks) for every frame of the batch.  E.g. 128 4K frames at out_stride = 8 MiB:
- * 1.4 GB; at out_stride = mi355_jpeg_scan_bound (84 MB): 5.5 GB.  MI355_JPEG_PIPELINE=tile
- * (strict / standard 4:4:4) needs 40 bytes per tile and nothing else. */
+ * size: it is cut into parts of ~16 4K frames' worth of pixels, each with 32-bit offsets of its own.
+ * Device memory the library allocates for a call (kept for later calls, grown on demand): per frame
+ * of a part 8 bytes per unit (units = 8x8 blocks x 3) plus 2 x min(9/16 x out_stride + 4 x units,
+ * 216 x units) + 0.25 MiB of string arena; one such set per part while the sets fit a quarter of the
+ * free device memory (at most 32 GB), otherwise as many as fit and parts take turns (a little slower:
+ * a part then waits for the tail kernels of the part whose set it reuses); plus 12 bytes per tile (64
+ * blocks) for every frame.  E.g. 128 4K frames at out_stride = 8 MiB: 8 parts, 5.7 GB; at out_stride =
+ * mi355_jpeg_scan_bound (84 MB): 22 GB.  MI355_JPEG_PIPELINE=tile (strict / standard 4:4:4) needs 40
+ * bytes per tile and nothing else. */
 int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx *ctx, const void *d_rgb, uint32_t W, uint32_t H,
                                   uint32_t n_frames, uint32_t flags, void *d_out,
                                   size_t out_stride, uint64_t *d_bits, void *stream);
@@ -274,7 +276,12 @@ int mi355_jpeg_stuff_device(mi355_jpeg_ctx *ctx, const void *d_scan, const uint6
  * entry of device_ids (an id may repeat: several workers on one GPU); each worker takes
  * a contiguous slab of frames and streams it through the device in chunks with
  * H2D(k+1) || encode(k) || D2H(k-1) on separate HIP streams.  Same results as
- * mi355_jpeg_encode_scan frame by frame. */
+ * mi355_jpeg_encode_scan frame by frame.
+ *
+ * The pool is persistent: worker threads (pinned to the CPUs of their GPU's NUMA node where
+ * /sys/bus/pci/devices/<bus id>/numa_node says which), contexts, streams, events and device
+ * buffers are made once and reused by every call; device buffers only grow.  A pool is driven
+ * from one host thread at a time. */
 typedef struct mi355_jpeg_pool mi355_jpeg_pool;
 /* device_ids NULL: every visible device once. */
 int mi355_jpeg_pool_create(const int *device_ids, int n_workers, mi355_jpeg_pool **pool);
@@ -282,11 +289,28 @@ void mi355_jpeg_pool_destroy(mi355_jpeg_pool *pool);
 int mi355_jpeg_pool_workers(mi355_jpeg_pool *pool);
 int mi355_jpeg_pool_set_quant(mi355_jpeg_pool *pool, const uint32_t qlum[64], const uint32_t qchrom[64]);
 int mi355_jpeg_pool_set_quality(mi355_jpeg_pool *pool, int quality);
+/* Streaming callers: register the host buffers they reuse (frame rings, output slabs) once; encode calls whose
+ * rgb / out lie inside a registered range do no registration work of their own.  Memory that is not registered
+ * this way is registered for the duration of each call (each buffer as one range, on the calling thread).  The
+ * memory must stay allocated until it is unregistered or the pool is destroyed. */
+int mi355_jpeg_pool_register(mi355_jpeg_pool *pool, void *ptr, size_t bytes);
+int mi355_jpeg_pool_unregister(mi355_jpeg_pool *pool, void *ptr);
 /* out: frame f at out + f*out_stride; bits[f] its bit count.  seconds (may be NULL)
  * receives the wall time of the call (PCIe-inclusive). */
 int mi355_jpeg_pool_encode(mi355_jpeg_pool *pool, const uint8_t *rgb, uint32_t W, uint32_t H,
                            uint32_t n_frames, uint32_t flags, uint8_t *out, size_t out_stride,
                            uint64_t *bits, double *seconds);
+/* The same with a per-frame status array (may be NULL): frame_status[f] = MI355_OK, or MI355_E_CAPACITY /
+ * MI355_E_CATEGORY for a frame that did not fit out_stride / holds a coefficient without a code (bits[f] =
+ * UINT64_MAX, out bytes undefined).  Every other frame of the batch is returned in full, whatever shard it was
+ * in; the call returns the first such error (MI355_OK if none). */
+int mi355_jpeg_pool_encode_ex(mi355_jpeg_pool *pool, const uint8_t *rgb, uint32_t W, uint32_t H,
+                              uint32_t n_frames, uint32_t flags, uint8_t *out, size_t out_stride,
+                              uint64_t *bits, int *frame_status, double *seconds);
+/* Test hook: what the pool has created since it exists -- counts[0] device / pinned allocations, [1] host-memory
+ * registrations, [2] streams + events, [3] encode calls.  A second call of the same shape on a pool whose buffers
+ * are registered adds to [3] only. */
+int mi355_jpeg_pool_debug_counts(mi355_jpeg_pool *pool, uint64_t counts[4]);
 
 /* ---- measurement ------------------------------------------------------- */
 /* mode 0: off (default).  mode 1: HIP events around every stage of each encode

@@ -55,7 +55,8 @@ ABI_SYMBOLS = [
     "mi355_jpeg_probe_samples", "mi355_jpeg_probe_coefficients", "mi355_jpeg_probe_unit_bits",
     "mi355_jpeg_entropy_only", "mi355_jpeg_set_profiling", "mi355_jpeg_last_timings",
     "mi355_jpeg_profile_summary", "mi355_jpeg_synth_lcg_device", "mi355_jpeg_stuff_device", "mi355_jpeg_pool_create", "mi355_jpeg_pool_destroy", "mi355_jpeg_pool_workers",
-    "mi355_jpeg_pool_set_quant", "mi355_jpeg_pool_set_quality", "mi355_jpeg_pool_encode",
+    "mi355_jpeg_pool_set_quant", "mi355_jpeg_pool_set_quality", "mi355_jpeg_pool_encode", "mi355_jpeg_pool_encode_ex",
+    "mi355_jpeg_pool_register", "mi355_jpeg_pool_unregister", "mi355_jpeg_pool_debug_counts",
     "mi355_jpeg_set_encode_waves", "mi355_jpeg_wrap_jfif", "mi355_jpeg_scan_bound_flags",
     "mi355_jpeg_last_call_launches", "mi355_jpeg_screen_stats",
     # the reference's stage functions one by one (host/mi355_stage_api.cpp wraps them in the reference's signatures)
@@ -131,6 +132,10 @@ def lib():
         L.mi355_jpeg_pool_set_quant.argtypes = [vp, vp, vp]
         L.mi355_jpeg_pool_set_quality.argtypes = [vp, C.c_int]
         L.mi355_jpeg_pool_encode.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, u64p, C.POINTER(C.c_double)]
+        L.mi355_jpeg_pool_encode_ex.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, u64p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.mi355_jpeg_pool_register.argtypes = [vp, vp, sz]
+        L.mi355_jpeg_pool_unregister.argtypes = [vp, vp]
+        L.mi355_jpeg_pool_debug_counts.argtypes = [vp, u64p]
         for name in ABI_SYMBOLS:  # fail at load time, not at first use, if a symbol is missing
             getattr(L, name)
         _lib = L
@@ -362,6 +367,30 @@ class Pool:
         qlum = np.ascontiguousarray(qlum, np.uint32).reshape(64)
         qchrom = np.ascontiguousarray(qchrom, np.uint32).reshape(64)
         _check(lib().mi355_jpeg_pool_set_quant(self._h, qlum.ctypes.data, qchrom.ctypes.data))
+
+    def register(self, array):
+        """Pin a numpy array for the pool's DMA until unregister() / close() (streaming callers: buffers they reuse)."""
+        _check(lib().mi355_jpeg_pool_register(self._h, array.ctypes.data, array.nbytes))
+
+    def unregister(self, array):
+        _check(lib().mi355_jpeg_pool_unregister(self._h, array.ctypes.data))
+
+    def debug_counts(self):
+        """(device/pinned allocations, host registrations, streams + events, encode calls) since the pool exists."""
+        c = (C.c_uint64 * 4)()
+        _check(lib().mi355_jpeg_pool_debug_counts(self._h, c))
+        return tuple(int(x) for x in c)
+
+    def encode_into(self, frames, out, flags=F_DEFAULT):
+        """frames [n,H,W,3] uint8 -> out [n,cap] uint8 (both caller-owned, e.g. registered).  Returns
+        (bits list, per-frame status list, seconds, return code) without raising on per-frame errors."""
+        n, H, W, _ = frames.shape
+        bits = (C.c_uint64 * n)()
+        st = (C.c_int * n)()
+        secs = C.c_double()
+        rc = lib().mi355_jpeg_pool_encode_ex(self._h, frames.ctypes.data, W, H, n, flags, out.ctypes.data, out.shape[1],
+                                             bits, st, C.byref(secs))
+        return [int(b) for b in bits], [int(x) for x in st], secs.value, rc
 
     def encode(self, frames, flags=F_DEFAULT, cap=None):
         """frames: uint8 [n,H,W,3].  Returns (out [n,cap] uint8, bits list, seconds)."""

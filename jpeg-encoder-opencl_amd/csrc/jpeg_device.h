@@ -47,8 +47,7 @@ struct ScreenParams {
     uint32_t prio_from_wg;  // k_screen_encode: workgroups >= this raise their issue priority (0xFFFFFFFF: none)
     uint32_t stagger;       // k_screen_encode: those workgroups start this many s_sleep(127) (~3.4 us each) late (0: none)
     uint32_t* status;
-    uint32_t* tile_bits;    // [frame][tile] bit totals, accumulated with atomics (zero on entry)
-    uint32_t* frame_err;    // [frame] error flags of this launch's frames (bit 0 category, bit 1 arena; zero on entry) or nullptr
+    uint32_t* tile_bits;    // [frame][tile] bit totals, accumulated with atomics (zero on entry); bit 31: a unit of the tile had an error
     uint32_t* coefs;        // probe output (tiled coefficient layout) or nullptr
     uint8_t* samples;       // probe output (padded YCbCr image, interleaved) or nullptr
     unsigned long long* stamps;  // diagnostic build only (-DMI355_STAMPS): [wave][8] phase cycle sums
@@ -101,7 +100,7 @@ hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, uint32_t* tile_bit
                             uint64_t* tile_off, uint8_t* out, uint64_t out_stride,
                             uint64_t* frame_bits, uint32_t* status, uint32_t* reset_counters,
                             bool rearm_tiles, uint64_t* chunk_tot,
-                            uint32_t* frame_err /* per-frame flags: a flagged or over-capacity frame gets bits = ~0; re-armed; or nullptr */,
+                            bool flag_frames /* a frame over capacity or with a poisoned tile total (bit 31) gets bits = ~0 */,
                             hipStream_t s);
 // Frames above 8192 tiles are scanned by scan_chunks(g) workgroups each (4096 tiles per chunk); their totals need
 // scan_chunks(g) words of scratch per frame (`chunk_tot`; nullptr: one workgroup per frame).

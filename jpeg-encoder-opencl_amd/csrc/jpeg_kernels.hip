@@ -191,9 +191,12 @@ __global__ void __launch_bounds__(NT)
     k_tile_scan(Geom g, uint32_t* __restrict__ tile_bits, uint64_t* __restrict__ tile_off,
                 uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ frame_bits,
                 uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters, uint32_t rearm_tiles,
-                uint32_t* __restrict__ frame_err) {
+                uint32_t flag_frames) {
     constexpr uint32_t kPer = 4;  // consecutive tiles per thread and chunk
     __shared__ uint32_t s_wave[NT / 64];
+    __shared__ uint32_t s_poison;
+    if (threadIdx.x == 0) s_poison = 0;
+    uint32_t poison = 0;  // bit 31 of a tile total: a unit of that tile had an error (k_screen_encode, k_dc_heads)
     __builtin_amdgcn_s_setprio(3);  // short, on the stream's critical path, resident next to encode kernels
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t frame = blockIdx.x;
@@ -211,7 +214,8 @@ __global__ void __launch_bounds__(NT)
         uint32_t v[kPer], sum = 0;
 #pragma unroll
         for (uint32_t k = 0; k < kPer; ++k) {
-            v[k] = i0 + k < g.tiles ? ((next[k] + pad) & ~pad) : 0u;
+            poison |= next[k];
+            v[k] = i0 + k < g.tiles ? (((next[k] & 0x7fffffffu) + pad) & ~pad) : 0u;
             sum += v[k];
             const uint32_t in = i0 + NT * kPer + k;
             next[k] = in < g.tiles ? tb[in] : 0u;
@@ -241,18 +245,15 @@ __global__ void __launch_bounds__(NT)
         }
         carry += total;
     }
+    if (poison & 0x80000000u) atomicOr(&s_poison, 1u);
+    __syncthreads();
     if (tid == 0) {
         to[g.tiles] = carry;
         const bool over = ((carry + 31) >> 5) * 4 > out_stride;
         if (over) atomicOr(status, 2u);  // MI355_E_CAPACITY
-        // Per-frame verdict: a frame that does not fit, or that a kernel flagged (a size without a code, arena exhausted),
-        // gets the bit count ~0 and is skipped by the merge; the other frames of the call are complete and valid.
-        bool flagged = false;
-        if (frame_err) {
-            flagged = frame_err[frame] != 0;
-            frame_err[frame] = 0;  // re-armed for the next call
-        }
-        frame_bits[frame] = (over || flagged) ? ~0ull : carry;
+        // Per-frame verdict: a frame that does not fit, or with a poisoned tile total (a size without a code, arena
+        // exhausted), gets the bit count ~0 and is skipped by the merge; the other frames of the call are complete and valid.
+        frame_bits[frame] = (flag_frames && (over || s_poison)) ? ~0ull : carry;
         // the screened pipeline's arena counter is consumed by now: re-arm it
         if (reset_counters && frame == 0) reset_counters[0] = 0;
     }
@@ -278,14 +279,20 @@ __global__ void __launch_bounds__(1024)
     const uint32_t pad = (g.flags & 8u) ? 7u : 0u;
     const uint32_t i0 = c * kChunkTiles + tid * 4;
     uint32_t v[4], sum = 0;
+    __shared__ uint32_t s_poison;
+    if (tid == 0) s_poison = 0;
+    uint32_t poison = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
-        v[k] = i0 + k < g.tiles ? ((tb[i0 + k] + pad) & ~pad) : 0u;
+        const uint32_t raw = i0 + k < g.tiles ? tb[i0 + k] : 0u;
+        poison |= raw;
+        v[k] = i0 + k < g.tiles ? (((raw & 0x7fffffffu) + pad) & ~pad) : 0u;
         sum += v[k];
     }
     const uint32_t incl = wave_incl_scan(sum, lane);
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
+    if (poison & 0x80000000u) atomicOr(&s_poison, 1u);
     uint32_t pre = 0, total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < 16; ++w) {
@@ -302,20 +309,22 @@ __global__ void __launch_bounds__(1024)
         }
         run += v[k];
     }
-    if (tid == 0) chunk_tot[(size_t)frame * chunks + c] = total;
+    __syncthreads();
+    if (tid == 0) chunk_tot[(size_t)frame * chunks + c] = total | ((uint64_t)s_poison << 63);  // bit 63: a poisoned tile in the chunk
 }
 __global__ void __launch_bounds__(1024)
     k_tile_fix(Geom g, uint64_t* __restrict__ tile_off, const uint64_t* __restrict__ chunk_tot, uint32_t chunks,
                uint8_t* __restrict__ out, uint64_t out_stride, uint64_t* __restrict__ frame_bits,
-               uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters, uint32_t* __restrict__ frame_err) {
+               uint32_t* __restrict__ status, uint32_t* __restrict__ reset_counters, uint32_t flag_frames) {
     __builtin_amdgcn_s_setprio(3);
     const uint32_t tid = threadIdx.x;
     const uint32_t c = blockIdx.x, frame = blockIdx.y;
     uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
     uint32_t* outw = reinterpret_cast<uint32_t*>(out + (size_t)frame * out_stride);
     const uint64_t* ct = chunk_tot + (size_t)frame * chunks;
+    constexpr uint64_t kTot = ~(1ull << 63);
     uint64_t before = 0;
-    for (uint32_t k = 0; k < c; ++k) before += ct[k];
+    for (uint32_t k = 0; k < c; ++k) before += ct[k] & kTot;
     const uint32_t i0 = c * kChunkTiles + tid * 4;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
@@ -328,16 +337,13 @@ __global__ void __launch_bounds__(1024)
         }
     }
     if (c + 1 == chunks && tid == 0) {
-        const uint64_t total = before + ct[c];
+        const uint64_t total = before + (ct[c] & kTot);
         to[g.tiles] = total;
         const bool over = ((total + 31) >> 5) * 4 > out_stride;
         if (over) atomicOr(status, 2u);  // MI355_E_CAPACITY
-        bool flagged = false;
-        if (frame_err) {  // see k_tile_scan
-            flagged = frame_err[frame] != 0;
-            frame_err[frame] = 0;
-        }
-        frame_bits[frame] = (over || flagged) ? ~0ull : total;
+        uint64_t poison = 0;  // see k_tile_scan
+        for (uint32_t k = 0; k < chunks; ++k) poison |= ct[k];
+        frame_bits[frame] = (flag_frames && (over || (poison >> 63))) ? ~0ull : total;
         if (reset_counters && frame == 0) reset_counters[0] = 0;
     }
 }
@@ -497,19 +503,19 @@ hipError_t launch_unit_sizes(const Geom& g, uint32_t n_frames, const uint32_t* c
 hipError_t launch_tile_scan(const Geom& g, uint32_t n_frames, uint32_t* tile_bits,
                             uint64_t* tile_off, uint8_t* out, uint64_t out_stride,
                             uint64_t* frame_bits, uint32_t* status, uint32_t* reset_counters,
-                            bool rearm_tiles, uint64_t* chunk_tot, uint32_t* frame_err, hipStream_t s) {
+                            bool rearm_tiles, uint64_t* chunk_tot, bool flag_frames, hipStream_t s) {
     if (g.tiles <= 8192) {
         hipLaunchKernelGGL(k_tile_scan<256>, dim3(n_frames), dim3(256), 0, s, g, tile_bits, tile_off, out,
-                           out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u, frame_err);
+                           out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u, flag_frames ? 1u : 0u);
     } else if (chunk_tot) {  // several workgroups per frame, two launches
         const uint32_t chunks = scan_chunks(g);
         hipLaunchKernelGGL(k_tile_chunks, dim3(chunks, n_frames), dim3(1024), 0, s, g, tile_bits, tile_off, chunk_tot,
                            chunks, rearm_tiles ? 1u : 0u);
         hipLaunchKernelGGL(k_tile_fix, dim3(chunks, n_frames), dim3(1024), 0, s, g, tile_off, chunk_tot, chunks, out,
-                           out_stride, frame_bits, status, reset_counters, frame_err);
+                           out_stride, frame_bits, status, reset_counters, flag_frames ? 1u : 0u);
     } else {
         hipLaunchKernelGGL(k_tile_scan<1024>, dim3(n_frames), dim3(1024), 0, s, g, tile_bits, tile_off, out,
-                           out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u, frame_err);
+                           out_stride, frame_bits, status, reset_counters, rearm_tiles ? 1u : 0u, flag_frames ? 1u : 0u);
     }
     return hipGetLastError();
 }

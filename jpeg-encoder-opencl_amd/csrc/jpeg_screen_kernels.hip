@@ -30,6 +30,16 @@ namespace mi355 {
 
 constexpr uint32_t kEncWaves = 4;
 
+// An error in a unit also poisons its tile's bit total (bit 31, never reached by the sums): k_tile_scan then knows WHICH
+// frame failed.  (MI355_NO_POISON: A/B builds only.)
+#ifdef MI355_NO_POISON
+#define POISON_TILE() (void)0
+#define POISON_FT() (void)0
+#else
+#define POISON_TILE() atomicOr(&sp.tile_bits[(size_t)frame * g.tiles + tile], 0x80000000u)
+#define POISON_FT() atomicOr(&sp.tile_bits[ft], 0x80000000u)
+#endif
+
 // Diagnostic build (make STAMPS=1): s_memtime stamps at the phase boundaries of a wave
 // iteration, summed per wave and written to sp.stamps.  Never in the shipped kernel.
 #ifdef MI355_STAMPS
@@ -390,10 +400,9 @@ __global__ void __launch_bounds__(256, 2)
         uint32_t nw = pkr.words();
         STAMP(2);
         const bool oversize = nw > kSlotRows;
-        if (!ok && active) {  // MI355_E_CATEGORY
-            atomicOr(sp.status, 1u);
-            if (sp.frame_err) atomicOr(&sp.frame_err[frame], 1u);
-        }
+        // (an error also poisons the tile's bit total -- bit 31, never reached by the sums -- which is how k_tile_scan
+        // learns WHICH frame failed without this kernel carrying a per-frame flag array)
+        if (!ok && active) atomicOr(sp.status, 1u), POISON_TILE();  // MI355_E_CATEGORY
         if (!active) nw = 0;
 
         // Total bits of the unit = DC symbol + AC string.  The DC difference needs the previous
@@ -405,10 +414,7 @@ __global__ void __launch_bounds__(256, 2)
             uint32_t ubits = aclen;
             auto count = [&](uint32_t, uint32_t len) { ubits += len; };
             const bool dc_ok = lane == 0 || put_dc(dc - pred, s_dc[ct], count);
-            if (!dc_ok && active) {  // MI355_E_CATEGORY
-                atomicOr(sp.status, 1u);
-                if (sp.frame_err) atomicOr(&sp.frame_err[frame], 1u);
-            }
+            if (!dc_ok && active) atomicOr(sp.status, 1u), POISON_TILE();  // MI355_E_CATEGORY
             if (!active) ubits = 0;
             ubits = wave_sum(ubits);
             if (lane == 0 && ubits) atomicAdd(&sp.tile_bits[(size_t)frame * g.tiles + tile], ubits);
@@ -422,10 +428,8 @@ __global__ void __launch_bounds__(256, 2)
         const uint32_t off = base + incl - need;
         const bool fits = base != 0xFFFFFFFFu;
         if (!fits) {
-            if (lane == 0) {  // MI355_E_CAPACITY (strings beyond 9/4 of the output capacity: the output could not hold them either)
-                atomicOr(sp.status, 2u);
-                if (sp.frame_err) atomicOr(&sp.frame_err[frame], 2u);
-            }
+            // MI355_E_CAPACITY (strings beyond 9/4 of the output capacity: the output could not hold them either)
+            if (lane == 0) atomicOr(sp.status, 2u), POISON_TILE();
         } else {
 #ifdef MI355_DIAG_NOARENA  // timing experiment only (wrong output): no AC strings written
             const uint32_t ncopy = 0u;
@@ -496,10 +500,7 @@ __global__ void __launch_bounds__(64)
         const int dc = meta_dc(sp.meta[u0].y);
         uint32_t len = 0;
         auto count = [&](uint32_t, uint32_t l) { len += l; };
-        if (!put_dc(dc - pred, s_dcf[luma ? 0 : 1], count)) {  // MI355_E_CATEGORY
-            atomicOr(sp.status, 1u);
-            if (sp.frame_err) atomicOr(&sp.frame_err[ft / g.tiles], 1u);
-        }
+        if (!put_dc(dc - pred, s_dcf[luma ? 0 : 1], count)) atomicOr(sp.status, 1u), POISON_FT();  // MI355_E_CATEGORY
         atomicAdd(&sp.tile_bits[ft], len);
     }
 }

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -116,10 +118,10 @@ struct mi355_jpeg_ctx {
     // batches are encoded as two halves: the tail kernels of the first half run on `side` under the
     // block-encode kernel of the second half
     hipStream_t side = nullptr;
-    hipEvent_t ev_half = nullptr, ev_side = nullptr, ev_set[2] = {nullptr, nullptr};
+    hipEvent_t ev_half = nullptr, ev_side = nullptr;
+    std::vector<hipEvent_t> ev_set;  // per workspace set: its last part's tail kernels are done
     uint32_t batch_parts = 0xFFFFu;  // MI355_JPEG_BATCH_PARTS (1..8): upper limit of the parts of a batch (1 = off)
-    uint32_t* d_frame_err = nullptr;  // [frames] per-frame error flags of the four-launch pipeline (zero between calls)
-    size_t frame_err_cap = 0;
+
     uint32_t qlum[64], qchrom[64];
     mi355_huff_table huff[4];
     mi355_huff_table huff_std[4];  // standard mode (MI355_F_STANDARD): Annex K proper unless the caller set a table
@@ -149,7 +151,8 @@ struct mi355_jpeg_ctx {
     double* d_qconst = nullptr;     // [2][64][4] accept thresholds for the current tables
     float* d_qconst_f = nullptr;    // [2 maps][2][16][8] fp32 first-look scale factors and thresholds
     uint32_t* d_lut2 = nullptr;     // [2 modes][2][66][16] whole AC symbols for |value| <= 31
-    uint32_t* d_counters = nullptr; // [0..1] arena overflow-pool words of the two workspace sets ([2..7] unused)
+    uint32_t* d_counters = nullptr; // [64] arena overflow-pool words, one per part in flight
+    uint32_t max_sets = 0;          // MI355_JPEG_MAX_SETS (tests): upper limit of the workspace sets of a batch (0 = none)
     unsigned long long* d_stats = nullptr;  // [0] second looks, [1] exact units (mi355_jpeg_screen_stats)
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
     uint8_t* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // scratch of the stage-by-stage entry points
@@ -425,7 +428,6 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.stats = c->d_stats;
     sp.status = c->d_status;
     sp.tile_bits = c->d_tile_bits;
-    sp.frame_err = nullptr;
     sp.coefs = coefs;
     sp.samples = nullptr;
     sp.stamps = nullptr;
@@ -488,7 +490,7 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
     // invariant: d_tile_bits is all zero between API calls (the screened pipeline accumulates into it)
     HIP_TRY(launch_tile_scan(g, n_frames, c->d_tile_bits, c->d_tile_off, d_out, out_stride, d_bits,
                              c->d_status, nullptr, true,
-                             scan_chunks(g) ? c->d_tile_off + ((size_t)g.tiles + 1) * n_frames : nullptr, nullptr, s));
+                             scan_chunks(g) ? c->d_tile_off + ((size_t)g.tiles + 1) * n_frames : nullptr, false, s));
     record(c, 3, s);
     HIP_TRY(launch_emit(g, n_frames, c->d_coefs, c->d_lut, c->d_unit_off, c->d_tile_off, d_out,
                         out_stride, c->d_status, c->emit_lds_words, s));
@@ -498,19 +500,20 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
 
 // One part of a batch: frames [f0, f0 + nf).  Parts alternate between two sets of {meta, arena, overflow counter}:
 // part i + 2 reuses the set of part i once that part's tail kernels are done.
+constexpr uint32_t kCounters = 64;  // overflow counters: part i uses i % 64 (its tile scan re-arms it long before part i + 64)
 struct BatchPart {
     uint32_t f0, nf;
     ArenaPlan plan;
-    uint32_t set;  // 0 / 1
+    uint32_t set;      // workspace set of this part
+    uint32_t counter;  // its overflow-pool counter (re-armed by the part's tile scan)
 };
 
 ScreenParams part_params(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p, size_t set_meta, size_t set_arena) {
     ScreenParams sp = screen_params(c, g, p.nf, p.plan, nullptr);
     sp.meta = c->d_meta + (size_t)p.set * set_meta;
     sp.arena = c->d_arena + (size_t)p.set * set_arena;
-    sp.counters = c->d_counters + p.set;
+    sp.counters = c->d_counters + p.counter;
     sp.tile_bits = c->d_tile_bits + (size_t)p.f0 * g.tiles;
-    sp.frame_err = c->d_frame_err + p.f0;
     return sp;
 }
 
@@ -521,7 +524,7 @@ int launch_tails(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p, const Scr
     HIP_TRY(launch_tile_scan(g, p.nf, sp.tile_bits, c->d_tile_off + (size_t)p.f0 * (g.tiles + 1),
                              d_out + (size_t)p.f0 * out_stride, out_stride, d_bits + p.f0, c->d_status, sp.counters,
                              true, scan_chunks(g) ? c->d_tile_off + ((size_t)g.tiles + 1) * batch_frames + (size_t)p.f0 * scan_chunks(g) : nullptr,
-                             sp.frame_err, s));
+                             true, s));
     if (rec) record(c, 3, s);
     HIP_TRY(launch_merge(g, p.nf, sp.meta, sp.arena, sp.lut, c->d_tile_off + (size_t)p.f0 * (g.tiles + 1),
                          d_out + (size_t)p.f0 * out_stride, out_stride, d_bits + p.f0, c->emit_lds_words, s));
@@ -572,18 +575,34 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     const ArenaPlan big = plan_arena(c, g, max_nf, (size_t)max_nf * frame_words);
     const size_t set_arena = (big.total_words + 63) & ~(size_t)63;
     const size_t set_meta = (size_t)g.tiles * g.passes * 64 * max_nf;
-    const uint32_t nsets = nparts > 1 ? 2 : 1;
+    // Sets of {metadata, arena}: one per part while they fit a budget (a quarter of the free device memory, at most
+    // 32 GB), otherwise as many as fit (at least 2) and part i reuses the set of part i - nsets once that part's tail
+    // kernels are done.  (Reuse costs: the wait for the side stream between two block-encode launches keeps them from
+    // running back to back -- 8 % on the bench with two alternating sets -- so sets are only shared when they must be.)
+    uint32_t nsets = nparts;
+    if (nparts > 2) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0, (void)hipGetLastError();
+        free_b += c->meta_cap * sizeof(uint2) + c->arena_cap * sizeof(uint32_t);  // what this context holds already counts as free
+        size_t budget = free_b / 4 < ((size_t)32 << 30) ? free_b / 4 : ((size_t)32 << 30);
+        const size_t set_bytes = set_meta * sizeof(uint2) + set_arena * sizeof(uint32_t);
+        const size_t fit = set_bytes ? budget / set_bytes : nparts;
+        nsets = (uint32_t)(fit < 2 ? 2 : (fit < nparts ? fit : nparts));
+        if (c->max_sets && nsets > c->max_sets) nsets = c->max_sets;  // tests
+    }
     if (set_arena > 0xFFFFFFFFull) return MI355_E_ARG;  // (cannot happen: parts were sized for it)
     int e;
     if ((e = ensure(c->d_meta, c->meta_cap, set_meta * nsets))) return e;
     if ((e = ensure(c->d_arena, c->arena_cap, set_arena * nsets))) return e;
-    if ((e = ensure(c->d_frame_err, c->frame_err_cap, (size_t)n_frames, true))) return e;
     if (nparts > 1 && !c->side) {
         HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_set[0], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_set[1], hipEventDisableTiming));
+    }
+    while (nsets < nparts && c->ev_set.size() < nsets) {  // only batches that share sets need them
+        hipEvent_t ev = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c->ev_set.push_back(ev);
     }
     record(c, 0, s);
     c->last_launches = nparts;
@@ -592,9 +611,10 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         part.f0 = (uint32_t)(((uint64_t)n_frames * i) / nparts);
         part.nf = (uint32_t)(((uint64_t)n_frames * (i + 1)) / nparts) - part.f0;
         part.plan = plan_arena(c, g, part.nf, (size_t)part.nf * frame_words);
-        part.set = i & 1u;
+        part.set = i % nsets;
+        part.counter = i % kCounters;
         const ScreenParams sp = part_params(c, g, part, set_meta, set_arena);
-        if (i >= 2) HIP_TRY(hipStreamWaitEvent(s, c->ev_set[part.set], 0));  // the tails of part i - 2 are done with this set
+        if (i >= nsets) HIP_TRY(hipStreamWaitEvent(s, c->ev_set[part.set], 0));  // the tails of part i - nsets are done with this set
         HIP_TRY(launch_screen_encode(g, part.nf, d_rgb + (size_t)part.f0 * g.frame_stride, sp, false, c->screen_waves, s));
         if (i + 1 == nparts) {  // the last part's tails stay on the caller's stream
             record(c, 1, s);
@@ -603,7 +623,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
             HIP_TRY(hipEventRecord(c->ev_half, s));
             HIP_TRY(hipStreamWaitEvent(c->side, c->ev_half, 0));
             if ((e = launch_tails(c, g, part, sp, d_out, out_stride, d_bits, c->side, false, n_frames))) return e;
-            HIP_TRY(hipEventRecord(c->ev_set[part.set], c->side));
+            if (i + nsets < nparts) HIP_TRY(hipEventRecord(c->ev_set[part.set], c->side));
         }
     }
     if (nparts > 1) {
@@ -689,6 +709,7 @@ struct Knobs {
     uint32_t emit_lds_words = 4096;
     double tau_scale = 1.0;
     uint32_t batch_parts = 0xFFFFu;
+    uint32_t max_sets = 0;
     int pipeline = 0;
     uint32_t screen_waves = 0;  // 0: the device's default
 };
@@ -719,6 +740,7 @@ bool read_knobs(Knobs* k) {
         else k->tau_scale = x;
     }
     if (knob_uint("MI355_JPEG_BATCH_PARTS", 1, 8, &kv)) k->batch_parts = (uint32_t)kv;
+    if (knob_uint("MI355_JPEG_MAX_SETS", 2, 64, &kv)) k->max_sets = (uint32_t)kv;
     if (const char* pl = getenv("MI355_JPEG_PIPELINE")) {
         if (!strcmp(pl, "tile")) k->pipeline = 1;
         else if (!strcmp(pl, "launches")) k->pipeline = 0;
@@ -788,6 +810,7 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     c->emit_lds_words = kn.emit_lds_words;
     c->tau_scale = kn.tau_scale;
     c->batch_parts = kn.batch_parts;
+    c->max_sets = kn.max_sets;
     c->pipeline = kn.pipeline;
     if (c->n_cus > 0) c->tile_wgs = (uint32_t)c->n_cus;
     if (kn.screen_waves) (void)mi355_jpeg_set_encode_waves(c, kn.screen_waves);  // one place derives every grid from it
@@ -800,12 +823,12 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst_f, 512 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut2, 4 * 66 * 16 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, 8 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->d_counters, 64 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_stats, 2 * sizeof(unsigned long long)) != hipSuccess)
         e = MI355_E_ALLOC;
     if (!e) e = hip_err(hipMemset(c->d_stats, 0, 2 * sizeof(unsigned long long)));
     if (!e) e = hip_err(hipMemset(c->d_status, 0, sizeof(uint32_t)));
-    if (!e) e = hip_err(hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t)));
+    if (!e) e = hip_err(hipMemset(c->d_counters, 0, 64 * sizeof(uint32_t)));
     if (!e) e = upload_afrag(c);
     if (!e) e = upload_tables(c);
     if (!e) e = hip_err(hipDeviceSynchronize());  // every fill and table copy above has landed
@@ -828,7 +851,7 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
                     c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
                     c->d_counters, c->d_meta,     c->d_arena,  c->d_lut2,     c->d_qconst_f,
-                    c->d_stuff_counts, c->d_stuff_offs, c->d_qzz, c->d_stats, c->d_rec, c->d_ticket, c->d_ovf, c->d_frame_err};
+                    c->d_stuff_counts, c->d_stuff_offs, c->d_qzz, c->d_stats, c->d_rec, c->d_ticket, c->d_ovf};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : c->d_stage)
@@ -1355,36 +1378,127 @@ extern "C" {
 //
 // Frames are independent (DC predictors start at 0 per frame, utils.cpp:665), so a batch
 // shards over GPUs with no exchange at all.  Worker w owns frames [lo_w, hi_w) and moves them
-// through its GPU in chunks: three streams, double-buffered device memory, user memory
-// registered with HIP for the duration of the call so that H2D / D2H are true DMA.
+// through its GPU in chunks: three streams, double-buffered device memory, host memory registered
+// with HIP so that H2D / D2H are true DMA.  Everything a worker needs lives in the pool and is made
+// once: its thread (pinned to the CPUs of the GPU's NUMA node), context, streams, events and device
+// buffers (grown on demand, never shrunk).  Host ranges the caller registers with
+// mi355_jpeg_pool_register stay registered across calls; memory that is not is registered for the
+// duration of one call, like before.
 
 }  // extern "C"
 
-#include <chrono>
-#include <thread>
+#include <sched.h>
 
-struct mi355_jpeg_pool {
-    std::vector<mi355_jpeg_ctx*> ctx;
-};
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
 
 namespace {
 
 struct PoolJob {
-    mi355_jpeg_ctx* c;
-    const uint8_t* rgb;
-    uint32_t W, H, lo, hi, flags;
-    uint8_t* out;
-    size_t out_stride;
-    uint64_t* bits;
-    int rc;
+    const uint8_t* rgb = nullptr;
+    uint32_t W = 0, H = 0, lo = 0, hi = 0, flags = 0;
+    uint8_t* out = nullptr;
+    size_t out_stride = 0;
+    uint64_t* bits = nullptr;
+    int* frame_status = nullptr;
+    int rc = MI355_OK;
 };
 
-void pool_worker(PoolJob* j) {
+struct PoolWorker {
+    mi355_jpeg_pool* pool = nullptr;
+    mi355_jpeg_ctx* c = nullptr;
+    int numa_node = -1;
+    // persistent device side
+    uint8_t *d_in[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
+    uint64_t *d_bits[2] = {nullptr, nullptr}, *h_bits = nullptr;
+    size_t in_cap[2] = {0, 0}, out_cap[2] = {0, 0}, bits_cap[2] = {0, 0}, hbits_cap = 0;
+    hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    // the worker thread and its mailbox
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    PoolJob* job = nullptr;  // set by pool_encode, cleared by the worker when done
+    bool quit = false;
+};
+
+}  // namespace
+
+struct mi355_jpeg_pool {
+    std::vector<PoolWorker*> w;
+    std::mutex reg_mu;
+    std::vector<std::pair<uintptr_t, size_t>> registered;  // host ranges registered through the pool
+    // what the pool has created since it exists (mi355_jpeg_pool_debug_counts): device allocations, host registrations,
+    // streams + events, encode calls
+    std::atomic<unsigned long long> n_alloc{0}, n_register{0}, n_objects{0}, n_calls{0};
+};
+
+namespace {
+
+// CPUs of the NUMA node a GPU hangs off, from sysfs (best effort: -1 / empty when the platform does not say)
+int gpu_numa_node(int device) {
+    char bus[32] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) return -1;
+    for (char* p = bus; *p; ++p) *p = (char)tolower(*p);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+bool pin_to_numa_node(int node) {
+    if (node < 0) return false;
+    const std::string path = "/sys/devices/system/node/node" + std::to_string(node) + "/cpulist";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char buf[4096] = {0};
+    const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int any = 0;
+    for (char* p = buf; *p && *p != '\n';) {  // "0-15,32-47"
+        char* end = nullptr;
+        long a = strtol(p, &end, 10), b2 = a;
+        if (end == p) break;
+        p = end;
+        if (*p == '-') {
+            b2 = strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long k = a; k <= b2 && k < CPU_SETSIZE; ++k) CPU_SET((int)k, &set), ++any;
+        if (*p == ',') ++p;
+    }
+    return any && sched_setaffinity(0, sizeof set, &set) == 0;
+}
+
+template <typename T>
+bool pool_ensure(mi355_jpeg_pool* p, T*& ptr, size_t& cap, size_t need) {
+    if (ptr && need <= cap) return true;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    if (hipMalloc((void**)&ptr, need * sizeof(T)) != hipSuccess) return false;
+    p->n_alloc++;
+    cap = need;
+    return true;
+}
+
+void pool_run(PoolWorker* w, PoolJob* j) {
     j->rc = MI355_OK;
     if (j->lo >= j->hi) return;
-    mi355_jpeg_ctx* c = j->c;
-    auto fail = [&](int rc) { j->rc = rc; };
-    if (hipSetDevice(c->device) != hipSuccess) return fail(MI355_E_NO_DEVICE);
+    mi355_jpeg_ctx* c = w->c;
+    mi355_jpeg_pool* pool = w->pool;
+    if (hipSetDevice(c->device) != hipSuccess) {
+        j->rc = MI355_E_NO_DEVICE;
+        return;
+    }
     const size_t fbytes = (size_t)j->W * j->H * 3;
     size_t dstride = (j->out_stride + 3) & ~(size_t)3;
     if (dstride < 8) dstride = 8;
@@ -1392,37 +1506,44 @@ void pool_worker(PoolJob* j) {
     uint32_t chunk = (uint32_t)((256u << 20) / fbytes);
     if (chunk < 1) chunk = 1;
     if (chunk > j->hi - j->lo) chunk = j->hi - j->lo;
-    uint8_t *d_in[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
-    uint64_t *d_bits[2] = {nullptr, nullptr}, *h_bits = nullptr;
-    hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_cmp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     int rc = MI355_OK;
     auto H = [&](hipError_t e) {
         if (e != hipSuccess && rc == MI355_OK) rc = MI355_E_HIP - (int)e;
         return e == hipSuccess;
     };
-    for (int b = 0; b < 2 && rc == MI355_OK; ++b) {
-        H(hipMalloc((void**)&d_in[b], fbytes * chunk));
-        H(hipMalloc((void**)&d_out[b], dstride * chunk));
-        H(hipMalloc((void**)&d_bits[b], sizeof(uint64_t) * chunk));
-        H(hipEventCreateWithFlags(&ev_in[b], hipEventDisableTiming));
-        H(hipEventCreateWithFlags(&ev_cmp[b], hipEventDisableTiming));
-        H(hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming));
+    if (!w->s_in) {  // first job of this worker: streams and events, once
+        H(hipStreamCreateWithFlags(&w->s_in, hipStreamNonBlocking));
+        H(hipStreamCreateWithFlags(&w->s_cmp, hipStreamNonBlocking));
+        H(hipStreamCreateWithFlags(&w->s_out, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            H(hipEventCreateWithFlags(&w->ev_in[b], hipEventDisableTiming));
+            H(hipEventCreateWithFlags(&w->ev_cmp[b], hipEventDisableTiming));
+            H(hipEventCreateWithFlags(&w->ev_out[b], hipEventDisableTiming));
+        }
+        pool->n_objects += 9;
     }
-    H(hipHostMalloc((void**)&h_bits, sizeof(uint64_t) * chunk * 2, hipHostMallocDefault));
-    H(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
-    H(hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking));
-    H(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
-    // register the caller's slabs so that the copies are asynchronous DMA (best effort)
-    const uint8_t* in_lo = j->rgb + (size_t)j->lo * fbytes;
-    uint8_t* out_lo = j->out + (size_t)j->lo * j->out_stride;
-    const bool reg_in = hipHostRegister((void*)in_lo, fbytes * (j->hi - j->lo), hipHostRegisterDefault) == hipSuccess;
-    const bool reg_out =
-        hipHostRegister((void*)out_lo, j->out_stride * (j->hi - j->lo), hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();
-
+    for (int b = 0; b < 2 && rc == MI355_OK; ++b)
+        if (!pool_ensure(pool, w->d_in[b], w->in_cap[b], fbytes * chunk) || !pool_ensure(pool, w->d_out[b], w->out_cap[b], dstride * chunk) ||
+            !pool_ensure(pool, w->d_bits[b], w->bits_cap[b], (size_t)chunk))
+            rc = MI355_E_ALLOC;
+    if (rc == MI355_OK && (!w->h_bits || w->hbits_cap < (size_t)chunk * 2)) {
+        if (w->h_bits) (void)hipHostFree(w->h_bits);
+        w->h_bits = nullptr;
+        if (H(hipHostMalloc((void**)&w->h_bits, sizeof(uint64_t) * chunk * 2, hipHostMallocDefault))) {
+            w->hbits_cap = (size_t)chunk * 2;
+            pool->n_alloc++;
+        }
+    }
+    uint8_t *const *d_in = w->d_in, *const *d_out = w->d_out;
+    uint64_t *const *d_bits = w->d_bits, *h_bits = w->h_bits;
+    hipStream_t s_in = w->s_in, s_cmp = w->s_cmp, s_out = w->s_out;
+    hipEvent_t *ev_in = w->ev_in, *ev_cmp = w->ev_cmp, *ev_out = w->ev_out;
+    // (caller memory that is not registered through the pool was registered for this call by pool_encode, as ONE range
+    // per buffer: slabs registered worker by worker share pages at their ends, and a page unpinned by the worker that
+    // finishes first is a page the other worker's DMA still targets)
     const uint32_t nchunks = (j->hi - j->lo + chunk - 1) / chunk;
     auto frames_of = [&](uint32_t k) { uint32_t a = j->lo + k * chunk; return (a + chunk <= j->hi ? chunk : j->hi - a); };
+    int frame_rc = MI355_OK;  // a frame that does not fit / has no code: the others still come back
     auto drain = [&](uint32_t k) {  // chunk k is encoded: fetch its bit counts, then its bytes
         const int b = (int)(k & 1);
         const uint32_t a = j->lo + k * chunk, nf = frames_of(k);
@@ -1432,11 +1553,18 @@ void pool_worker(PoolJob* j) {
         for (uint32_t f = 0; f < nf && rc == MI355_OK; ++f) {
             const uint64_t nb = h_bits[(size_t)b * chunk + f];
             j->bits[a + f] = nb;
-            const size_t bytes = (size_t)((nb + 7) / 8);
-            if (bytes > j->out_stride) {
-                rc = MI355_E_CAPACITY;
-                break;
+            if (nb == ~0ull) {  // flagged by the device (capacity or category: mi355_jpeg_sync below says which came first)
+                if (j->frame_status) j->frame_status[a + f] = MI355_E_CAPACITY;
+                if (frame_rc == MI355_OK) frame_rc = MI355_E_CAPACITY;
+                continue;
             }
+            const size_t bytes = (size_t)((nb + 7) / 8);
+            if (bytes > j->out_stride) {  // fits the 4-byte-rounded device slot, not the caller's
+                if (j->frame_status) j->frame_status[a + f] = MI355_E_CAPACITY;
+                if (frame_rc == MI355_OK) frame_rc = MI355_E_CAPACITY;
+                continue;
+            }
+            if (j->frame_status) j->frame_status[a + f] = MI355_OK;
             H(hipMemcpyAsync(j->out + (size_t)(a + f) * j->out_stride, d_out[b] + (size_t)f * dstride, bytes,
                              hipMemcpyDeviceToHost, s_out));
         }
@@ -1461,27 +1589,42 @@ void pool_worker(PoolJob* j) {
     }
     if (rc == MI355_OK) drain(nchunks - 1);
     if (s_out) (void)hipStreamSynchronize(s_out);
-    if (rc == MI355_OK) {
-        int e = mi355_jpeg_sync(c, s_cmp);
-        if (e) rc = e;
-    } else if (s_cmp) {
-        (void)hipStreamSynchronize(s_cmp);
+    if (s_in) (void)hipStreamSynchronize(s_in);
+    if (s_cmp) {
+        const int e = mi355_jpeg_sync(c, s_cmp);  // also clears the device-side status for the next call
+        if (rc == MI355_OK && e) {
+            rc = e;
+            if (j->frame_status && (e == MI355_E_CATEGORY || e == MI355_E_CAPACITY))
+                for (uint32_t f = j->lo; f < j->hi; ++f)
+                    if (j->bits[f] == ~0ull) j->frame_status[f] = e;  // the shard's first device-side error
+        }
     }
-    if (reg_in) (void)hipHostUnregister((void*)in_lo);
-    if (reg_out) (void)hipHostUnregister((void*)out_lo);
-    for (int b = 0; b < 2; ++b) {
-        if (d_in[b]) (void)hipFree(d_in[b]);
-        if (d_out[b]) (void)hipFree(d_out[b]);
-        if (d_bits[b]) (void)hipFree(d_bits[b]);
-        if (ev_in[b]) (void)hipEventDestroy(ev_in[b]);
-        if (ev_cmp[b]) (void)hipEventDestroy(ev_cmp[b]);
-        if (ev_out[b]) (void)hipEventDestroy(ev_out[b]);
+    if (rc == MI355_OK) rc = frame_rc;
+    j->rc = rc;
+}
+
+void pool_thread(PoolWorker* w) {
+    (void)hipSetDevice(w->c->device);
+    (void)pin_to_numa_node(w->numa_node);  // best effort: the copies' staging and the launches stay next to the GPU
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->job != nullptr || w->quit; });
+        if (w->quit) break;
+        PoolJob* j = w->job;
+        lk.unlock();
+        pool_run(w, j);
+        lk.lock();
+        w->job = nullptr;
+        w->cv.notify_all();
     }
-    if (h_bits) (void)hipHostFree(h_bits);
-    if (s_in) (void)hipStreamDestroy(s_in);
-    if (s_cmp) (void)hipStreamDestroy(s_cmp);
-    if (s_out) (void)hipStreamDestroy(s_out);
-    fail(rc);
+}
+
+bool pool_covers(mi355_jpeg_pool* p, const void* ptr, size_t bytes) {
+    std::lock_guard<std::mutex> g(p->reg_mu);
+    const uintptr_t a = (uintptr_t)ptr;
+    for (auto& r : p->registered)
+        if (a >= r.first && a + bytes <= r.first + r.second) return true;
+    return false;
 }
 
 }  // namespace
@@ -1509,7 +1652,17 @@ int mi355_jpeg_pool_create(const int* device_ids, int n_workers, mi355_jpeg_pool
             mi355_jpeg_pool_destroy(p);
             return e;
         }
-        p->ctx.push_back(c);
+        PoolWorker* w = new (std::nothrow) PoolWorker();
+        if (!w) {
+            mi355_jpeg_destroy(c);
+            mi355_jpeg_pool_destroy(p);
+            return MI355_E_ALLOC;
+        }
+        w->pool = p;
+        w->c = c;
+        w->numa_node = gpu_numa_node(id);
+        p->w.push_back(w);
+        w->th = std::thread(pool_thread, w);
     }
     *out = p;
     return MI355_OK;
@@ -1517,16 +1670,39 @@ int mi355_jpeg_pool_create(const int* device_ids, int n_workers, mi355_jpeg_pool
 
 void mi355_jpeg_pool_destroy(mi355_jpeg_pool* p) {
     if (!p) return;
-    for (auto* c : p->ctx) mi355_jpeg_destroy(c);
+    for (PoolWorker* w : p->w) {
+        {
+            std::lock_guard<std::mutex> g(w->mu);
+            w->quit = true;
+        }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+        (void)hipSetDevice(w->c->device);
+        for (int b = 0; b < 2; ++b) {
+            if (w->d_in[b]) (void)hipFree(w->d_in[b]);
+            if (w->d_out[b]) (void)hipFree(w->d_out[b]);
+            if (w->d_bits[b]) (void)hipFree(w->d_bits[b]);
+            if (w->ev_in[b]) (void)hipEventDestroy(w->ev_in[b]);
+            if (w->ev_cmp[b]) (void)hipEventDestroy(w->ev_cmp[b]);
+            if (w->ev_out[b]) (void)hipEventDestroy(w->ev_out[b]);
+        }
+        if (w->h_bits) (void)hipHostFree(w->h_bits);
+        if (w->s_in) (void)hipStreamDestroy(w->s_in);
+        if (w->s_cmp) (void)hipStreamDestroy(w->s_cmp);
+        if (w->s_out) (void)hipStreamDestroy(w->s_out);
+        mi355_jpeg_destroy(w->c);
+        delete w;
+    }
+    for (auto& r : p->registered) (void)hipHostUnregister((void*)r.first);
     delete p;
 }
 
-int mi355_jpeg_pool_workers(mi355_jpeg_pool* p) { return p ? (int)p->ctx.size() : 0; }
+int mi355_jpeg_pool_workers(mi355_jpeg_pool* p) { return p ? (int)p->w.size() : 0; }
 
 int mi355_jpeg_pool_set_quant(mi355_jpeg_pool* p, const uint32_t qlum[64], const uint32_t qchrom[64]) {
     if (!p) return MI355_E_ARG;
-    for (auto* c : p->ctx) {
-        int e = mi355_jpeg_set_quant(c, qlum, qchrom);
+    for (auto* w : p->w) {
+        int e = mi355_jpeg_set_quant(w->c, qlum, qchrom);
         if (e) return e;
     }
     return MI355_OK;
@@ -1534,33 +1710,97 @@ int mi355_jpeg_pool_set_quant(mi355_jpeg_pool* p, const uint32_t qlum[64], const
 
 int mi355_jpeg_pool_set_quality(mi355_jpeg_pool* p, int quality) {
     if (!p) return MI355_E_ARG;
-    for (auto* c : p->ctx) {
-        int e = mi355_jpeg_set_quality(c, quality);
+    for (auto* w : p->w) {
+        int e = mi355_jpeg_set_quality(w->c, quality);
         if (e) return e;
     }
     return MI355_OK;
 }
 
-int mi355_jpeg_pool_encode(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t n_frames,
-                           uint32_t flags, uint8_t* out, size_t out_stride, uint64_t* bits, double* seconds) {
-    if (!p || p->ctx.empty() || !rgb || !out || !bits || n_frames == 0) return MI355_E_ARG;
+int mi355_jpeg_pool_register(mi355_jpeg_pool* p, void* ptr, size_t bytes) {
+    if (!p || !ptr || !bytes) return MI355_E_ARG;
+    if (pool_covers(p, ptr, bytes)) return MI355_OK;
+    if (!p->w.empty()) HIP_TRY(hipSetDevice(p->w[0]->c->device));
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable));  // pinned for every device of the pool
+    p->n_register++;
+    std::lock_guard<std::mutex> g(p->reg_mu);
+    p->registered.push_back({(uintptr_t)ptr, bytes});
+    return MI355_OK;
+}
+
+int mi355_jpeg_pool_unregister(mi355_jpeg_pool* p, void* ptr) {
+    if (!p || !ptr) return MI355_E_ARG;
+    std::lock_guard<std::mutex> g(p->reg_mu);
+    for (size_t i = 0; i < p->registered.size(); ++i)
+        if (p->registered[i].first == (uintptr_t)ptr) {
+            p->registered.erase(p->registered.begin() + (long)i);
+            HIP_TRY(hipHostUnregister(ptr));
+            return MI355_OK;
+        }
+    return MI355_E_ARG;
+}
+
+int mi355_jpeg_pool_debug_counts(mi355_jpeg_pool* p, uint64_t counts[4]) {
+    if (!p || !counts) return MI355_E_ARG;
+    counts[0] = p->n_alloc, counts[1] = p->n_register, counts[2] = p->n_objects, counts[3] = p->n_calls;
+    return MI355_OK;
+}
+
+int mi355_jpeg_pool_encode_ex(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t n_frames,
+                              uint32_t flags, uint8_t* out, size_t out_stride, uint64_t* bits, int* frame_status,
+                              double* seconds) {
+    if (!p || p->w.empty() || !rgb || !out || !bits || n_frames == 0) return MI355_E_ARG;
     Geom g;
     int e = make_geom(W, H, flags, nullptr, &g);
     if (e) return e;
     const auto t0 = std::chrono::steady_clock::now();
-    const uint32_t nw = (uint32_t)p->ctx.size();
-    std::vector<PoolJob> jobs(nw);
-    std::vector<std::thread> th;
-    for (uint32_t w = 0; w < nw; ++w) {
-        const uint32_t lo = (uint32_t)((uint64_t)n_frames * w / nw), hi = (uint32_t)((uint64_t)n_frames * (w + 1) / nw);
-        jobs[w] = PoolJob{p->ctx[w], rgb, W, H, lo, hi, flags, out, out_stride, bits, MI355_OK};
-        th.emplace_back(pool_worker, &jobs[w]);
+    p->n_calls++;
+    const uint32_t nw = (uint32_t)p->w.size();
+    // Host memory the caller has not registered through the pool is registered here for the duration of the call --
+    // each buffer as ONE range, before any worker starts, released after the last one has finished (best effort:
+    // memory that is pinned already, e.g. by the caller's allocator, refuses and is fine as it is).
+    bool in_reg = pool_covers(p, rgb, (size_t)g.frame_stride * n_frames);
+    bool out_reg = pool_covers(p, out, out_stride * n_frames);
+    bool tmp_in = false, tmp_out = false;
+    (void)hipSetDevice(p->w[0]->c->device);
+    if (!in_reg) {
+        tmp_in = hipHostRegister((void*)rgb, (size_t)g.frame_stride * n_frames, hipHostRegisterPortable) == hipSuccess;
+        if (tmp_in) p->n_register++;
     }
-    for (auto& t : th) t.join();
+    if (!out_reg) {
+        tmp_out = hipHostRegister((void*)out, out_stride * n_frames, hipHostRegisterPortable) == hipSuccess;
+        if (tmp_out) p->n_register++;
+    }
+    (void)hipGetLastError();
+    std::vector<PoolJob> jobs(nw);
+    for (uint32_t w = 0; w < nw; ++w) {
+        PoolJob& jb = jobs[w];
+        jb.rgb = rgb, jb.W = W, jb.H = H, jb.flags = flags, jb.out = out, jb.out_stride = out_stride, jb.bits = bits;
+        jb.frame_status = frame_status;
+        jb.lo = (uint32_t)((uint64_t)n_frames * w / nw), jb.hi = (uint32_t)((uint64_t)n_frames * (w + 1) / nw);
+        PoolWorker* pw = p->w[w];
+        {
+            std::lock_guard<std::mutex> gk(pw->mu);
+            pw->job = &jb;
+        }
+        pw->cv.notify_all();
+    }
+    for (uint32_t w = 0; w < nw; ++w) {
+        PoolWorker* pw = p->w[w];
+        std::unique_lock<std::mutex> lk(pw->mu);
+        pw->cv.wait(lk, [&] { return pw->job == nullptr; });
+    }
+    if (tmp_in) (void)hipHostUnregister((void*)rgb);
+    if (tmp_out) (void)hipHostUnregister((void*)out);
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (auto& jb : jobs)
         if (jb.rc) return jb.rc;
     return MI355_OK;
+}
+
+int mi355_jpeg_pool_encode(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t n_frames,
+                           uint32_t flags, uint8_t* out, size_t out_stride, uint64_t* bits, double* seconds) {
+    return mi355_jpeg_pool_encode_ex(p, rgb, W, H, n_frames, flags, out, out_stride, bits, nullptr, seconds);
 }
 
 // ---- the reference's stage functions, one by one ---------------------------------------

@@ -45,6 +45,9 @@ def check_two_ranks(r):
         for k, b in enumerate(bits):
             assert b == ol.oracle_encode(ol.lcg_frame(64, 48, 1 + rank * 3 + k)).n_bits
     assert r["value"] > 0
+    # the N > 1 line is complete (cpu_baseline and the PCIe-inclusive leg were emitted at N = 1 only)
+    assert r["cpu_baseline"]["kind"] in ("port", "reference") and r["cpu_baseline"]["cores"] == 1 and r["cpu_baseline"]["value"] > 0
+    assert r["end_to_end"]["gpus"] == 2
 
 
 def test_two_ranks_without_a_launcher():
@@ -72,3 +75,12 @@ def test_a_dead_rank_fails_the_run():
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dead-rank-grace", "5"] + ARGS, env=env,
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 3, (out.returncode, out.stderr[-500:])
+
+
+def test_gpu_worker_emits_the_secondary_legs_at_every_n():
+    """Static check of the GPU worker (it cannot run here): cpu_baseline and end_to_end are not guarded by gpus == 1."""
+    src = open(BENCH).read()
+    body = src[src.index("def worker(args):"):src.index("def single_call_latency")]
+    assert 'line["cpu_baseline"] = base' in body and 'line["end_to_end"] = end_to_end_leg(' in body
+    for guard in ("if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline", "if rank == 0 and args.gpus == 1 and not args.quick"):
+        assert guard not in body

@@ -961,6 +961,33 @@ def test_per_frame_error_reporting(jpeg, monkeypatch, pipeline):
     e2.close()
 
 
+def test_parts_that_share_workspace_sets(jpeg, monkeypatch):
+    """A batch whose parts do not all get a workspace set of their own (MI355_JPEG_MAX_SETS=2 forces what a nearly
+    full device does by itself): part i reuses the set of part i - 2 after that part's tail kernels; same bits."""
+    monkeypatch.setenv("MI355_JPEG_MAX_SETS", "2")
+    e2 = jpeg.Encoder(0)
+    ql, qc = set_quality(e2, 50)
+    W, H, n = 1920, 1080, 256
+    gold = _golden(W, H, 50)
+    import torch
+    dev = torch.device("cuda", 0)
+    d_rgb = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    e2.synth_lcg_device(d_rgb.data_ptr(), W * H * 3, n, 1)
+    cap = 2 << 20
+    d_out = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
+    d_bits = torch.zeros(n, dtype=torch.int64, device=dev)
+    for _ in range(2):
+        e2.encode_scan_device(d_rgb.data_ptr(), W, H, n, d_out.data_ptr(), cap, d_bits.data_ptr())
+        e2.sync()
+    assert e2.last_call_parts() >= 4
+    bits = d_bits.cpu().numpy()
+    frames = d_rgb[[0, 100, 255]].cpu().numpy()
+    for k, f in enumerate((0, 100, 255)):
+        o = ol.oracle_encode(frames[k], ql, qc, True)
+        assert int(bits[f]) == o.n_bits and np.array_equal(d_out[f, :(o.n_bits + 7) // 8].cpu().numpy(), o.bits), f
+    e2.close()
+
+
 def test_batch_at_worst_case_capacity_is_accepted(jpeg, enc):
     """128 4K frames in ONE call with out_stride = mi355_jpeg_scan_bound (84 MB per frame, what
     the header recommends) used to be refused with MI355_E_ARG (the workspace was sized from the caller's capacity
@@ -992,3 +1019,58 @@ def test_batch_at_worst_case_capacity_is_accepted(jpeg, enc):
         assert enc.last_call_parts() >= n // 20
         del d_rgb, d_out, d_bits
         torch.cuda.empty_cache()
+
+
+def test_pool_is_persistent_and_reports_per_frame(jpeg):
+    """VERDICT r2 item 4 / weakness 8: the pool keeps its worker threads, contexts, streams, events and device buffers
+    across calls, and host buffers registered through it stay registered: a second call of the same shape creates
+    NOTHING (debug counters).  And a frame that does not fit its slot is reported per frame (status array, bits =
+    UINT64_MAX) while every other frame of the batch -- in either worker's shard -- comes back in full."""
+    pool = jpeg.Pool([0, 0])  # two workers on the one GPU of the box
+    assert pool.workers == 2
+    pool.set_quality(50)
+    W, H, n = 640, 360, 12
+    ql, qc = ol.quant_tables(50)
+    frames = np.stack([ol.lcg_frame(W, H, 300 + f) for f in range(n)])
+    orc = [ol.oracle_encode(frames[f], ql, qc, True) for f in range(n)]
+    cap = (max(o.n_bits for o in orc) + 7) // 8 + 64 & ~3
+    out = np.zeros((n, cap), np.uint8)
+    pool.register(frames)
+    pool.register(out)
+    bits, st, _, rc = pool.encode_into(frames, out)
+    assert rc == 0 and st == [0] * n
+    for f in range(n):
+        assert bits[f] == orc[f].n_bits and np.array_equal(out[f, :(bits[f] + 7) // 8], orc[f].bits), f
+    c1 = pool.debug_counts()
+    assert c1[0] > 0 and c1[1] == 2 and c1[2] == 18 and c1[3] == 1
+    out[:] = 0
+    bits, st, _, rc = pool.encode_into(frames, out)
+    c2 = pool.debug_counts()
+    assert c2[:3] == c1[:3] and c2[3] == 2, (c1, c2)  # no hipMalloc, no hipHostRegister, no stream / event
+    for f in range(n):
+        assert bits[f] == orc[f].n_bits and np.array_equal(out[f, :(bits[f] + 7) // 8], orc[f].bits), f
+    # memory that is NOT registered through the pool is registered per call, as before
+    out2 = np.zeros((n, cap), np.uint8)
+    bits, st, _, rc = pool.encode_into(frames, out2)
+    c3 = pool.debug_counts()
+    assert rc == 0 and c3[1] == c2[1] + 1 and c3[0] == c2[0] and np.array_equal(out2, out)  # out2 alone: frames is registered
+    # one frame that does not fit: near-flat frames around one noise frame, slots sized for the flat ones
+    yy, xx = np.mgrid[0:H, 0:W]
+    fl = np.stack([np.stack([120 + f + (xx // 40), 125 + (yy // 50) + f, 128 + 0 * xx], -1).astype(np.uint8) for f in range(n)])
+    fl[7] = frames[7]
+    orc2 = [ol.oracle_encode(fl[f], ql, qc, True) for f in range(n)]
+    cap2 = (max(o.n_bits for i, o in enumerate(orc2) if i != 7) + 7) // 8 + 64 & ~3
+    assert (orc2[7].n_bits + 7) // 8 > cap2
+    out3 = np.zeros((n, cap2), np.uint8)
+    bits, st, _, rc = pool.encode_into(fl, out3)
+    assert rc == jpeg.E_CAPACITY
+    assert st[7] == jpeg.E_CAPACITY and bits[7] == 0xFFFFFFFFFFFFFFFF
+    for f in range(n):
+        if f != 7:
+            assert st[f] == 0 and bits[f] == orc2[f].n_bits and np.array_equal(out3[f, :(bits[f] + 7) // 8], orc2[f].bits), f
+    # and the pool is clean again afterwards
+    bits, st, _, rc = pool.encode_into(frames, out)
+    assert rc == 0 and bits == [o.n_bits for o in orc]
+    pool.unregister(frames)
+    pool.unregister(out)
+    pool.close()

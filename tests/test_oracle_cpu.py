@@ -214,7 +214,7 @@ def test_abi_exports_every_declared_symbol(jpeg):
     for s in syms:
         assert hasattr(L, s), "libmi355jpeg.so does not export " + s
     assert sorted(jpeg.ABI_SYMBOLS) == syms
-    assert L.mi355_jpeg_abi_version() == 2
+    assert L.mi355_jpeg_abi_version() == 3
 
 
 def test_host_helpers_without_a_gpu(jpeg):

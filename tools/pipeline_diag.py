@@ -15,8 +15,10 @@ enc.synth_lcg_device(d_rgb.data_ptr(), W * H * 3, n, 1)
 cap = 8 << 20
 d_out = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
 d_bits = torch.zeros(n, dtype=torch.int64, device=dev)
+FLAGS = int(os.environ.get("MI355_DIAG_FLAGS", str(jpeg.F_DEFAULT)))  # e.g. 6 = MI355_F_STANDARD | MI355_F_420
+enc.set_quality(int(os.environ.get("MI355_DIAG_QUALITY", "50")))
 def go(k):
-    enc.encode_scan_device(d_rgb.data_ptr(), W, H, k, d_out.data_ptr(), cap, d_bits.data_ptr())
+    enc.encode_scan_device(d_rgb.data_ptr(), W, H, k, d_out.data_ptr(), cap, d_bits.data_ptr(), flags=FLAGS)
 res = {}
 for k in (1, n):
     go(k)
@@ -31,4 +33,4 @@ for k in (1, n):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     res["frames%d_us_per_frame" % k] = round(dt / k * 1e6, 2)
-print(json.dumps({"pipeline": os.environ.get("MI355_JPEG_PIPELINE"), **res}))
+print(json.dumps({"pipeline": os.environ.get("MI355_JPEG_PIPELINE"), "flags": FLAGS, **res}))
