@@ -73,6 +73,7 @@ struct TeamLds {
     uint32_t merged;                             // +1 by Cb and by Cr per tile, once they read nothing more of what the Y wave wrote
     uint32_t next_ticket;                        // the team's next tile (told at the meeting of a tile)
     uint32_t first_ticket[2];                    // the team's first tile of a frame (alternating: a frame may hold no tile for the team)
+    uint32_t first_frame[2];                     // and that frame (0xFFFFFFFF: no work left anywhere)
     uint32_t excl_lo, excl_hi;                   // the tile's bit offset in its frame
     uint32_t err[2];                             // category error seen by a wave of the team in this tile; and
     uint32_t big[2];                             // a wave of the team holds a string in its overflow area.  Indexed by the parity
@@ -430,23 +431,53 @@ __global__ void __launch_bounds__(kTileThreads)
         const uint32_t ptile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tl.pend[2]);
         return granule_load(tp.rec + ((size_t)pframe * g.tiles + (ptile - 1)) * kRecGranules + 3);
     };
-    for (uint32_t frame = group; frame < n_frames; frame += groups) {
+    // Frames: a team first works through its own list (group, group + G, ...), then HELPS: it looks for frames whose
+    // ticket counter has not run out and draws from them.  Without that the launch ends when the slowest frame's teams
+    // end -- a 128-frame launch lasted 12 % longer than its average wave.  (Any team may take any tile: tickets and
+    // look-back do not care who holds them.)
+    uint32_t own_next = group, helped = 0, predrawn = 0xFFFFFFFFu;
+    if (wg_draw) {  // one frame: the workgroup draws its teams' first tickets with one atomic (see above)
+        if (tid == 0) s_first = atomicAdd(&tp.ticket[0], kTeams);
+        __syncthreads();
+        predrawn = s_first + team;
+    }
+    for (;;) {
         // (the frame's pointers -- pixels, hand-off records, scan granules -- are formed from an opaque copy of `frame` in
         // the phase that uses them: as loop invariants of the tile loop they end up in VGPR pairs, spilled to scratch, and
         // every reload is an s_waitcnt vmcnt(0) that also waits for the sc1 loads in flight)
-        // first ticket of the frame: drawn by the team's first wave, told at a meeting.  One frame only: every team pulls
-        // from the same counter (it saturates at ~88 returning atomics per microsecond), so the workgroup draws its
-        // first tickets with one atomic.
-        if (wg_draw) {
-            if (tid == 0) s_first = atomicAdd(&tp.ticket[frame], kTeams);
-            __syncthreads();  // reached once by every wave: n_frames == 1
-            if (chan == 0 && lane == 0) tl.first_ticket[fpar] = s_first + team;
-        } else if (chan == 0 && lane == 0) {
-            tl.first_ticket[fpar] = atomicAdd(&tp.ticket[frame], 1u);
+        // Next frame and first ticket: chosen by the team's first wave, told at a meeting.
+        if (chan == 0) {
+            uint32_t nf = 0xFFFFFFFFu, nt = 0;
+            if (lane == 0) {
+                while (own_next < n_frames) {
+                    const uint32_t cand = own_next;
+                    own_next += groups;
+                    nt = predrawn != 0xFFFFFFFFu ? predrawn : atomicAdd(&tp.ticket[cand], 1u);
+                    predrawn = 0xFFFFFFFFu;
+                    if (nt < g.tiles) {
+                        nf = cand;
+                        break;
+                    }
+                }
+                while (nf == 0xFFFFFFFFu && helped + 1 < n_frames) {  // every other frame once, starting behind the own one
+                    ++helped;
+                    const uint32_t cand = (group + helped) % n_frames;
+                    if (__hip_atomic_load(&tp.ticket[cand], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.tiles) {
+                        nt = atomicAdd(&tp.ticket[cand], 1u);
+                        if (nt < g.tiles) nf = cand;
+                        else continue;
+                        --helped;  // look at this frame again when these tiles are done: it may still have some
+                    }
+                }
+                tl.first_ticket[fpar] = nt;
+                tl.first_frame[fpar] = nf;
+            }
         }
         m3.meet(lane, spin);
+        const uint32_t frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)tl.first_frame[fpar]);
         uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tl.first_ticket[fpar]);
         fpar ^= 1u;
+        if (frame == 0xFFFFFFFFu) break;
         while (t < g.tiles) {
             OPAQUE_LANE();
             uint32_t frame_s = frame;

@@ -965,6 +965,7 @@ def test_parts_that_share_workspace_sets(jpeg, monkeypatch):
     """A batch whose parts do not all get a workspace set of their own (MI355_JPEG_MAX_SETS=2 forces what a nearly
     full device does by itself): part i reuses the set of part i - 2 after that part's tail kernels; same bits."""
     monkeypatch.setenv("MI355_JPEG_MAX_SETS", "2")
+    monkeypatch.setenv("MI355_JPEG_PIPELINE", "launches")
     e2 = jpeg.Encoder(0)
     ql, qc = set_quality(e2, 50)
     W, H, n = 1920, 1080, 256
@@ -1016,7 +1017,8 @@ def test_batch_at_worst_case_capacity_is_accepted(jpeg, enc):
             assert ascii_sha(d_out[f, :(g[0] + 7) // 8].cpu().numpy(), g[0]) == g[1], (n, f)
             checked += 1
         assert checked >= 4
-        assert enc.last_call_parts() >= n // 20
+        if os.environ.get("MI355_JPEG_PIPELINE") != "tile":  # (the single-launch pipeline has no parts)
+            assert enc.last_call_parts() >= n // 20
         del d_rgb, d_out, d_bits
         torch.cuda.empty_cache()
 

@@ -1,0 +1,10 @@
+#!/bin/bash
+# GPU box helper (round 3): quick parity of both pipelines + timing of both
+set -e -o pipefail
+OUT=gpurun_out/$1; mkdir -p "$OUT"
+cd "$GRAFT_REPO_ROOT"
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "both_pipelines or per_frame or golden" > "$OUT/pytest_both.log" 2>&1 || { tail -40 "$OUT/pytest_both.log"; exit 1; }
+tail -2 "$OUT/pytest_both.log"
+for p in tile launches tile launches; do
+  MI355_JPEG_PIPELINE=$p timeout -k 10 300 python tools/pipeline_diag.py 128 | tee -a "$OUT/diag.log"
+done
