@@ -76,6 +76,10 @@ hipError_t launch_encode_tile(const Geom& g, uint32_t n_frames, const uint8_t* r
 uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves);
 hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,
                                 bool probe, uint32_t grid_waves, hipStream_t s);
+// the same kernel at three waves per SIMD (jpeg_wide_kernels.hip: one 11-wave workgroup per CU; strict and standard 4:4:4)
+uint32_t wide_grid_waves(const Geom& g, uint32_t n_frames, uint32_t max_wgs);
+hipError_t launch_screen_encode_wide(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp, uint32_t grid_waves,
+                                     hipStream_t s);
 hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams& sp, hipStream_t s);
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,
                         const uint32_t* lut, const uint64_t* tile_off,

@@ -497,131 +497,7 @@ __global__ void __launch_bounds__(kTileThreads)
 
             TSTAMP(0);
             // ---------------- samples: the wave's 64 blocks as four B operands ----------------
-            v4i A[2][kLookDigits];
-            uint32_t lane16 = lane * 16u;
-            asm volatile("" : "+v"(lane16));  // see load_pair_fragments
-            {
-                // Block coordinates of this lane's four blocks (16j + n) are walked, not stored; a first walk finds out
-                // whether the whole tile lies inside the image.
-                uint32_t bx0, by0;
-                {
-                    uint32_t b = tile * 64 + n;
-                    if (b >= g.N) b = g.N - 1;  // past the last block: any valid block will do, the lane is masked later
-                    by0 = b / g.nbx, bx0 = b - by0 * g.nbx;
-                }
-                auto next_block = [&](uint32_t& bx, uint32_t& by, int j /* the block reached */) {
-                    bx += 16;
-                    while (bx >= g.nbx) {
-                        bx -= g.nbx;
-                        ++by;
-                    }
-                    if (tile * 64 + 16 * j + n >= g.N) {
-                        bx = g.nbx - 1;
-                        by = g.N / g.nbx - 1;
-                    }
-                };
-                bool interior = true;
-                {
-                    uint32_t bx = bx0, by = by0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        interior = interior && (bx * 8 + 8 <= g.W) && (by * 8 + 8 <= g.H);
-                        if (j < 3) next_block(bx, by, j + 1);
-                    }
-                }
-                const bool fast = g.fast_rows && __all(interior);
-                uint32_t raw[12];  // raw RGB of unit-tile j+1 is fetched while unit-tile j is converted
-                uint32_t bx = bx0, by = by0;
-                if (fast) load_raw_rowpair(f, g, bx, by, gq, raw);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t pk[4];
-                    if (fast) {
-                        uint32_t cur[12];
-#pragma unroll
-                        for (int i = 0; i < 12; ++i) cur[i] = raw[i];
-                        if (j < 3) {
-                            next_block(bx, by, j + 1);
-                            load_raw_rowpair(f, g, bx, by, gq, raw);
-                        } else {
-                            load_pair_fragments(sp, lane16, 0, A);  // land while the last unit-tile is converted
-                        }
-                        if (chan == 0) convert_rowpair<0, STD>(cur, false, pk);
-                        else if (chan == 1) convert_rowpair<1, STD>(cur, avg, pk);
-                        else convert_rowpair<2, STD>(cur, avg, pk);
-                    } else {
-                        if (chan == 0) generic_rowpair<0, STD>(f, g, false, bx, by, gq, pk);
-                        else if (chan == 1) generic_rowpair<1, STD>(f, g, avg, bx, by, gq, pk);
-                        else generic_rowpair<2, STD>(f, g, avg, bx, by, gq, pk);
-                        if (j < 3) next_block(bx, by, j + 1);
-                        else load_pair_fragments(sp, lane16, 0, A);
-                    }
-                    // sum of the block's 64 samples (for the exact DC): 16 in this lane, then over the 4 row-pair lanes
-                    uint32_t ssum = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) ssum = __builtin_amdgcn_sad_u8(pk[i], 0u, ssum);
-                    ssum += __shfl_xor(ssum, 16);
-                    ssum += __shfl_xor(ssum, 32);
-                    if (gq == (uint32_t)j) dcsum = ssum;  // coefficient 0 of unit 16j+n is formed by the lane (n, gq == j)
-                    // level shift: sample - 128 as int8 == sample ^ 0x80
-                    B[j] = v4i{(int)(pk[0] ^ 0x80808080u), (int)(pk[1] ^ 0x80808080u), (int)(pk[2] ^ 0x80808080u),
-                               (int)(pk[3] ^ 0x80808080u)};
-                }
-            }
-
-            TSTAMP(1);
-            // ---------------- map + quantise + verify, row-tile pair by row-tile pair ----------------
-            OPAQUE_LANE();
-            s_mlo[lane] = 0;
-            s_mhi[lane] = 0;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int mtp = 0; mtp < 2; ++mtp) {
-                if (mtp == 1) load_pair_fragments(sp, lane16, 1, A);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bool amb = false;
-                    uint32_t qa[4], qb[4];  // low 16 bits = quantised value
-                    screen_quantise<STD>(A[0], B[j], sp, &s_qf[ct][4 * (2 * mtp) + gq][0], ct, 2 * mtp, gq, lane, qa, amb);
-                    screen_quantise<STD>(A[1], B[j], sp, &s_qf[ct][4 * (2 * mtp + 1) + gq][0], ct, 2 * mtp + 1, gq, lane, qb, amb);
-                    // zig-zag positions 16mt+4gq .. +3 of unit 16j+n -> row buffer
-                    i16a* const row = tb16 + (32 * mtp + 4 * gq) * 64 + row_unit_off(16 * j + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) row[r * 64] = (int16_t)qa[r], row[(16 + r) * 64] = (int16_t)qb[r];
-                    // non-zero bits, two values per instruction (see k_screen_encode): flags of positions 32mtp + 4gq + r
-                    // and 32mtp + 16 + 4gq + r at bits r and 16 + r, shifted in by 4gq
-                    uint32_t w = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const uint32_t pr = __builtin_amdgcn_perm(qb[r], qa[r], 0x05040100u);  // qa.lo16 | qb.lo16 << 16
-                        uint32_t fl;
-                        asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(fl) : "v"(pr));
-                        w |= fl << r;
-                    }
-                    if (mtp == 0) atomicOr(&s_mlo[16 * j + n], (w << (4 * gq)) & ~1u);
-                    else atomicOr(&s_mhi[16 * j + n], w << (4 * gq));
-                    if (amb) atomicOr(&s_mlo[16 * j + n], 1u);  // bit 0 (coefficient 0 is never walked) = "undecided unit"
-                }
-            }
-            {
-                // exact coefficient 0 of unit 16*gq + n.  Strict: c0 = fl(sum * SCALE_00), q0 = round(c0 / Q0)
-                // (utils.cpp:336,459).  Standard: row 0 of the true DCT is exactly 1/8,
-                // q0 = round-half-away(sum / (8 Q0)) in integers.
-                int q0;
-                if constexpr (STD) {
-                    const int sl = (int)dcsum - 8192;
-                    const uint32_t Q0 = (uint32_t)q0d, a0 = (uint32_t)(sl < 0 ? -sl : sl);
-                    const int n0 = (int)((a0 + 4u * Q0) / (8u * Q0));
-                    q0 = sl < 0 ? -n0 : n0;
-                } else {
-                    const double c0 = (double)((int)dcsum - 8192) * kScale00;
-                    q0 = (int)__builtin_round(c0 / q0d);
-                }
-                tb16[row_unit_off(16 * gq + n)] = (int16_t)q0;
-            }
-            __builtin_amdgcn_wave_barrier();
-
-            TSTAMP(2);
+#include "jpeg_transform_core.inc"
             // ---------------- walk phase: lane = block ----------------
             OPAQUE_LANE();
             if constexpr (!STD) {

@@ -168,7 +168,8 @@ struct mi355_jpeg_ctx {
     uint32_t* d_ovf = nullptr;
     size_t ovf_cap = 0;             // words
     uint32_t epoch = 0;
-    uint32_t tile_wgs = 256;        // workgroups of k_encode_tile (one per CU)
+    uint32_t tile_wgs = 256;        // workgroups of k_encode_tile / k_screen_encode_wide (one per CU)
+    int encode_shape = 0;           // block-encode kernel of the four-launch pipeline: 0 k_screen_encode (2 x 4 waves per CU), 1 k_screen_encode_wide (11 waves per CU)
     uint2* d_meta = nullptr;
     size_t meta_cap = 0;
     uint32_t* d_arena = nullptr;
@@ -393,9 +394,10 @@ struct ArenaPlan {
     uint32_t grid, region_words;
     size_t total_words;
 };
+bool wide_shape(const mi355_jpeg_ctx* c, const Geom& g) { return c->encode_shape == 1 && !is420(g); }
 ArenaPlan plan_arena(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, size_t need_words) {
     ArenaPlan p;
-    p.grid = screen_grid(g, n_frames, c->screen_waves);
+    p.grid = wide_shape(c, g) ? wide_grid_waves(g, n_frames, c->tile_wgs) : screen_grid(g, n_frames, c->screen_waves);
     p.region_words = (uint32_t)((need_words + p.grid - 1) / p.grid);
     p.total_words = (size_t)p.grid * p.region_words + need_words + (size_t)p.grid * 1024 + 64;
     return p;
@@ -615,7 +617,10 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         part.counter = i % kCounters;
         const ScreenParams sp = part_params(c, g, part, set_meta, set_arena);
         if (i >= nsets) HIP_TRY(hipStreamWaitEvent(s, c->ev_set[part.set], 0));  // the tails of part i - nsets are done with this set
-        HIP_TRY(launch_screen_encode(g, part.nf, d_rgb + (size_t)part.f0 * g.frame_stride, sp, false, c->screen_waves, s));
+        if (wide_shape(c, g))
+            HIP_TRY(launch_screen_encode_wide(g, part.nf, d_rgb + (size_t)part.f0 * g.frame_stride, sp, part.plan.grid, s));
+        else
+            HIP_TRY(launch_screen_encode(g, part.nf, d_rgb + (size_t)part.f0 * g.frame_stride, sp, false, c->screen_waves, s));
         if (i + 1 == nparts) {  // the last part's tails stay on the caller's stream
             record(c, 1, s);
             if ((e = launch_tails(c, g, part, sp, d_out, out_stride, d_bits, s, nparts == 1, n_frames))) return e;
@@ -710,6 +715,7 @@ struct Knobs {
     double tau_scale = 1.0;
     uint32_t batch_parts = 0xFFFFu;
     uint32_t max_sets = 0;
+    int encode_shape = 0;
     int pipeline = 0;
     uint32_t screen_waves = 0;  // 0: the device's default
 };
@@ -744,6 +750,11 @@ bool read_knobs(Knobs* k) {
     if (const char* pl = getenv("MI355_JPEG_PIPELINE")) {
         if (!strcmp(pl, "tile")) k->pipeline = 1;
         else if (!strcmp(pl, "launches")) k->pipeline = 0;
+        else bad = true;
+    }
+    if (const char* es = getenv("MI355_JPEG_ENCODE_SHAPE")) {
+        if (!strcmp(es, "wide")) k->encode_shape = 1;
+        else if (!strcmp(es, "classic")) k->encode_shape = 0;
         else bad = true;
     }
     if (knob_uint("MI355_JPEG_SCREEN_WAVES", 32, 8192, &kv)) {
@@ -811,6 +822,7 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     c->tau_scale = kn.tau_scale;
     c->batch_parts = kn.batch_parts;
     c->max_sets = kn.max_sets;
+    c->encode_shape = kn.encode_shape;
     c->pipeline = kn.pipeline;
     if (c->n_cus > 0) c->tile_wgs = (uint32_t)c->n_cus;
     if (kn.screen_waves) (void)mi355_jpeg_set_encode_waves(c, kn.screen_waves);  // one place derives every grid from it

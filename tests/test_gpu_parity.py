@@ -746,13 +746,16 @@ def test_screen_counters_are_exposed(jpeg):
     e2.close()
 
 
-@pytest.mark.parametrize("pipeline", ["tile", "launches"])
+@pytest.mark.parametrize("pipeline", ["tile", "launches", "launches-wide"])
 def test_both_pipelines_are_bit_identical(jpeg, monkeypatch, pipeline):
     """MI355_JPEG_PIPELINE=tile (the single-launch kernel of jpeg_tile_kernels.hip -- three waves per tile, in-kernel
     look-back scan + merge) and =launches (the default: block-encode kernel + three tail kernels) against the
     oracle: ragged sizes, one-tile and many-tile frames, batches (several frames per look-back group and several
     groups), high quality (strings longer than their LDS slot, tiles larger than the bit window), the capacity
     error, and the stage probes."""
+    if pipeline == "launches-wide":  # the four-launch pipeline with the 11-waves-per-CU block-encode kernel (jpeg_wide_kernels.hip)
+        monkeypatch.setenv("MI355_JPEG_ENCODE_SHAPE", "wide")
+        pipeline = "launches"
     monkeypatch.setenv("MI355_JPEG_PIPELINE", pipeline)
     e2 = jpeg.Encoder(0)
     rng = np.random.default_rng(7)
