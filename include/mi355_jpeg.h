@@ -53,7 +53,8 @@ enum mi355_jpeg_status {
 #define MI355_F_CDS 1u       /* run the 2x2 chroma averaging (performCDS, utils.cpp:113-141).
                                 Set = reference behaviour; clear = "4:4:4 (no subsample)" build convention */
 #define MI355_F_STANDARD 2u  /* SURVEY §8 f1 -- NOT a behaviour of the reference: a decodable baseline JPEG.
-                                True 8x8 DCT-II (as an exact fixed-point map, 2^-39), round-to-nearest colour
+                                True 8x8 DCT-II (as a fixed-point map of 23 fractional bits evaluated exactly on the
+                                matrix units, quotient by Q in fp32: the mode is defined by that arithmetic), round-to-nearest colour
                                 conversion, 4:4:4 unless MI355_F_420 (MI355_F_CDS is ignored), Annex K code tables proper (without
                                 the seven 17-bit entries of huffman.hpp:92-98), EOB omitted after a non-zero
                                 coefficient 63.  Files from mi355_jpeg_encode_jfif decode in libjpeg/PIL. */

@@ -632,10 +632,20 @@ __device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], con
     const v2f M2 = {12582912.0f, 12582912.0f};
     const v2f zA = fA * sA, zB = fB * sB;
     const v2f aA = zA + M2, aB = zB + M2;
+    const float aa[4] = {aA[0], aA[1], aB[0], aB[1]};
+    if constexpr (STD) {
+        // Standard mode IS this arithmetic (it is not a behaviour of the reference, so there is nothing to verify it
+        // against): the DCT-II as a fixed-point map of 23 fractional bits, evaluated exactly on the matrix units; the
+        // quotient by Q in fp32 -- two integer -> float conversions, one fma, one product, each rounded to nearest even --
+        // and the nearest integer of that by the 1.5 * 2^23 addition (ties to even).  The checker (oracle/jpeg_oracle.c,
+        // std_block) performs the same operations in the same order.
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qb[r] = __float_as_uint(aa[r]);  // 0x4B400000 + q
+        return;
+    }
     const v2f rA = aA - M2, rB = aB - M2;
     const v2f dA = zA - rA, dB = zB - rB;
     const float zz[4] = {zA[0], zA[1], zB[0], zB[1]};
-    const float aa[4] = {aA[0], aA[1], aB[0], aB[1]};
     const float dd[4] = {dA[0], dA[1], dB[0], dB[1]};
     bool a1[4];
 #pragma unroll
@@ -658,14 +668,7 @@ __device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], con
                 const double* qc = sp.qconst + ((size_t)ct * 64 + 16 * mt + 4 * gq + r) * 4;
                 const double y1 = (double)acc[2][r] * 65536.0 + (double)t[r];                 // exact (< 2^37)
                 const double y2 = y1 * 65536.0 + (double)(acc1[r] * 256 + acc0[r]);          // exact (< 2^53)
-                if constexpr (STD) {
-                    // standard mode is DEFINED by the fixed-point map: decide exactly in integers
-                    const long long Y = (long long)y2;
-                    const unsigned long long Dq = (unsigned long long)sp.qnat_zz[ct * 64 + 16 * mt + 4 * gq + r] << 39;
-                    const unsigned long long a = (unsigned long long)(Y < 0 ? -Y : Y);
-                    const unsigned long long nn = (2 * a + Dq) / (2 * Dq);
-                    qb[r] = (uint32_t)(Y < 0 ? -(long long)nn : (long long)nn);
-                } else {
+                {
                     const double z = y2 * qc[2];
                     const double tt = __builtin_fabs(z) + 0.5;
                     const double fr = tt - __builtin_floor(tt);

@@ -520,15 +520,53 @@ static int std_unit(const int32_t zz[64], int32_t dc_diff, int chroma, struct or
     return nbits;
 }
 
-/* one 8x8 block of level-shifted samples -> quantised zig-zag row, in exact integers */
-static void std_block(const int32_t p[64], const uint32_t *q, const uint8_t zz[64], const int64_t *dct,
+/* One 8x8 block of level-shifted samples -> quantised zig-zag row.  Standard mode is DEFINED by this arithmetic (it is
+ * not a behaviour of the reference): the DCT-II as a fixed-point map -- `dct` = round(D * 2^39), of which the top three
+ * balanced base-256 digits are kept, i.e. 23 fractional bits -- evaluated exactly in integers; then the quotient by Q in
+ * single precision: acc4 and t = 256 acc3 + acc2 converted to float (round to nearest even), fv = fmaf(acc4, 2^16, t),
+ * zf = fv * (float)(2^-23 / Q), and the nearest integer of zf through the 1.5 * 2^23 addition (ties to even).  Row 0 is
+ * exactly sum / 8: q0 = round-half-away(sum / (8 Q)) in integers.  The HIP path (screen_quantise<STD>,
+ * jpeg_screen_devfn.h) performs the same operations in the same order, so the two agree bit for bit. */
+static void std_digits(int64_t x, int d[5]) { /* balanced base-256 digits, least significant first (tools/gen_screen_tables.py) */
+    for (int l = 0; l < 5; ++l) {
+        int64_t m = (x + 128) % 256;
+        if (m < 0) m += 256;
+        const int64_t r = m - 128;
+        d[l] = (int)r;
+        x = (x - r) / 256;
+    }
+}
+/* dig: [3][64][64] = digits 4, 3, 2 of the table (std_digit_table) */
+static void std_digit_table(const int64_t *dct, int32_t *dig) {
+    for (int i = 0; i < 4096; ++i) {
+        int d[5];
+        std_digits(dct[i], d);
+        dig[i] = d[4], dig[4096 + i] = d[3], dig[8192 + i] = d[2];
+    }
+}
+static void std_block(const int32_t p[64], const uint32_t *q, const uint8_t zz[64], const int32_t *dig,
                       int32_t *row) {
-    for (int R = 0; R < 64; ++R) {
-        int64_t Y = 0;
-        for (int s = 0; s < 64; ++s) Y += dct[R * 64 + s] * p[s];
-        int64_t D = (int64_t)q[zz[R]] << 39, a = Y < 0 ? -Y : Y;
-        int64_t n = (2 * a + D) / (2 * D);
-        row[R] = (int32_t)(Y < 0 ? -n : n);
+    {
+        int64_t sum = 0;
+        for (int s = 0; s < 64; ++s) sum += p[s];
+        const int64_t Q0 = q[zz[0]], a = sum < 0 ? -sum : sum, n = (a + 4 * Q0) / (8 * Q0);
+        row[0] = (int32_t)(sum < 0 ? -n : n);
+    }
+    for (int R = 1; R < 64; ++R) {
+        int32_t acc4 = 0, acc3 = 0, acc2 = 0;
+        for (int s = 0; s < 64; ++s)
+            acc4 += dig[R * 64 + s] * p[s], acc3 += dig[4096 + R * 64 + s] * p[s], acc2 += dig[8192 + R * 64 + s] * p[s];
+        const int32_t t = acc3 * 256 + acc2;
+        const float fv = fmaf((float)acc4, 65536.0f, (float)t);
+        const float sf = (float)(ldexp(1.0, 16 - 39) / (double)q[zz[R]]);
+        const float zf = fv * sf;
+        volatile float a = zf + 12582912.0f; /* one rounding, in single precision */
+        union {
+            float f;
+            uint32_t u;
+        } b;
+        b.f = a;
+        row[R] = (int32_t)(int16_t)(b.u & 0xffffu); /* the float's bits are 0x4B400000 + q */
     }
 }
 
@@ -558,6 +596,8 @@ static int32_t *std_transform(const uint8_t *rgb, size_t W, size_t H, const uint
     free(img);
     uint8_t zz[64];
     orc_zigzag_order(zz);
+    int32_t *dig = (int32_t *)malloc(3 * 4096 * sizeof(int32_t));
+    std_digit_table(dct, dig);
     /* Row order of `zig`.  4:4:4: chan*M + block (like the strict path).  4:2:0: the luma blocks in
      * scan order (4*mcu + k, k = 2*(row in MCU) + (column in MCU)), then Cb (4M + mcu), then Cr (5M + mcu). */
     if (!subsample) {
@@ -568,7 +608,7 @@ static int32_t *std_transform(const uint8_t *rgb, size_t W, size_t H, const uint
                     int32_t p[64];
                     for (int s = 0; s < 64; ++s)
                         p[s] = (int32_t)pad[3 * ((by * 8 + s / 8) * Wp + bx * 8 + s % 8) + c] - 128;
-                    std_block(p, c == 0 ? qlum : qchrom, zz, dct, zig + ((size_t)c * M + by * bw + bx) * 64);
+                    std_block(p, c == 0 ? qlum : qchrom, zz, dig, zig + ((size_t)c * M + by * bw + bx) * 64);
                 }
     } else {
         const size_t mw = Wp / 16;
@@ -579,7 +619,7 @@ static int32_t *std_transform(const uint8_t *rgb, size_t W, size_t H, const uint
                 for (int k = 0; k < 4; ++k) {
                     const size_t x0 = mx * 16 + (k & 1) * 8, y0 = my * 16 + (k >> 1) * 8;
                     for (int s = 0; s < 64; ++s) p[s] = (int32_t)pad[3 * ((y0 + s / 8) * Wp + x0 + s % 8)] - 128;
-                    std_block(p, qlum, zz, dct, zig + (4 * mcu + k) * 64);
+                    std_block(p, qlum, zz, dig, zig + (4 * mcu + k) * 64);
                 }
                 for (int c = 1; c < 3; ++c) {
                     /* 2x2 mean of the converted samples, rounded to nearest (ties up) */
@@ -589,11 +629,12 @@ static int32_t *std_transform(const uint8_t *rgb, size_t W, size_t H, const uint
                                         pad[3 * ((y + 1) * Wp + x) + c] + pad[3 * ((y + 1) * Wp + x + 1) + c];
                         p[s] = ((sum + 2) >> 2) - 128;
                     }
-                    std_block(p, qchrom, zz, dct, zig + ((size_t)(3 + c) * M + mcu) * 64);
+                    std_block(p, qchrom, zz, dig, zig + ((size_t)(3 + c) * M + mcu) * 64);
                 }
             }
     }
     free(pad);
+    free(dig);
     return zig;
 }
 

@@ -1,9 +1,10 @@
 """Standard mode: a decodable baseline JPEG.  NOT a behaviour of the
-reference -- parity unpinned by it.  The mode is defined in integer arithmetic
-(tests/golden/std_dct_q39.i64 = the true DCT-II rounded to 2^-39; round-half-away
-quantisation; round-to-nearest colour conversion), so the checker in oracle/ and the HIP
-path must agree bit for bit; what ties it to the outside world is that libjpeg (PIL)
-decodes the files to the picture an independent JPEG encoder produces."""
+reference -- parity unpinned by it.  The mode is defined by its arithmetic (the true DCT-II as a fixed-point
+map: tests/golden/std_dct_q39.i64, of which the top three base-256 digits = 23 fractional bits are used,
+evaluated exactly in integers; the quotient by Q in single precision, nearest integer with ties to even;
+round-to-nearest colour conversion), so the checker in oracle/ and the HIP path must agree bit for bit;
+what ties it to the outside world is that libjpeg (PIL) decodes the files to the picture an independent
+JPEG encoder produces, and that the quantised values are within one of the exact quotient's rounding."""
 import io
 import os
 
@@ -213,11 +214,13 @@ def test_gpu_standard_jfif_decodes(jpeg, enc):
 
 
 @pytest.mark.gpu
-def test_gpu_standard_second_look_is_exact(jpeg, monkeypatch):
-    """With the first look disabled (debug margin factor) every coefficient is decided by the
-    exact integer second look; nothing may change and nothing goes to the fix-up kernel."""
+def test_gpu_standard_mode_has_nothing_to_verify(jpeg, monkeypatch):
+    """Standard mode is DEFINED by its arithmetic (3-digit fixed-point DCT on the matrix units, fp32 quotient): the
+    accept margins of the strict screen play no part in it -- with the margins blown up (debug factor: every strict
+    coefficient would go to the second look) the standard results do not change and neither counter moves."""
     monkeypatch.setenv("MI355_JPEG_SCREEN_TAU_SCALE", "1e9")
     e2 = jpeg.Encoder(0)
+    e2.screen_stats(reset=True)
     for (W, H, q) in [(320, 200, 50), (100, 37, 92)]:
         rgb = ol.lcg_frame(W, H, 11)
         ql, qc = ol.quant_tables(q)
@@ -226,7 +229,37 @@ def test_gpu_standard_second_look_is_exact(jpeg, monkeypatch):
         assert np.array_equal(e2.probe_coefficients(rgb, jpeg.F_STANDARD).astype(np.int32), o.zigzag)
         bits, nb = e2.encode_scan(rgb, jpeg.F_STANDARD)
         assert nb[0] == o.n_bits and np.array_equal(bits[0], o.bits)
+    assert e2.screen_stats() == (0, 0)
     e2.close()
+
+
+def test_checker_quantiser_is_within_one_of_the_exact_quotient():
+    """What the fp32 definition costs in accuracy: against round-half-away of the exact 2^-39 fixed-point DCT divided by Q
+    the defined value differs by at most 1, and only when the exact quotient sits within 2e-3 of a half-integer."""
+    rng = np.random.default_rng(3)
+    T = ol.std_dct_table().astype(object)
+    for q in (50, 90, 100):
+        ql, qc = ol.quant_tables(q)
+        rgb = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+        o = ol.oracle_std_encode(rgb, ql, qc, KEEP)
+        # luma plane as the checker converts it
+        r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+        y = np.minimum((299 * r + 587 * g + 114 * b + 500) // 1000, 255) - 128
+        zz = ol.zigzag_order()
+        bad = 0
+        for blk in range(64):
+            by, bx = divmod(blk, 8)
+            p = y[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8].reshape(64).astype(object)
+            for R in range(1, 64):
+                Y = int(sum(int(T[R][s]) * int(p[s]) for s in range(64)))
+                D = int(ql.reshape(64)[zz[R]]) << 39
+                exact = (2 * abs(Y) + D) // (2 * D) * (1 if Y >= 0 else -1)
+                got = int(o.zigzag[blk, R])
+                if got != exact:
+                    bad += 1
+                    frac = abs(abs(Y) / D - np.floor(abs(Y) / D) - 0.5)
+                    assert abs(got - exact) == 1 and frac < 2e-3, (q, blk, R, got, exact, frac)
+        assert bad < 64 * 63 // 100
 
 
 @pytest.mark.gpu

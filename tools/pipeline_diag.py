@@ -12,7 +12,7 @@ enc = jpeg.Encoder(0)
 dev = torch.device("cuda", 0)
 d_rgb = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
 enc.synth_lcg_device(d_rgb.data_ptr(), W * H * 3, n, 1)
-cap = 8 << 20
+cap = int(os.environ.get("MI355_DIAG_CAP_MB", "8")) << 20
 d_out = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
 d_bits = torch.zeros(n, dtype=torch.int64, device=dev)
 FLAGS = int(os.environ.get("MI355_DIAG_FLAGS", str(jpeg.F_DEFAULT)))  # e.g. 6 = MI355_F_STANDARD | MI355_F_420
