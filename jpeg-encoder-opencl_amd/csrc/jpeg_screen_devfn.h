@@ -637,8 +637,8 @@ __device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], con
         // Standard mode IS this arithmetic (it is not a behaviour of the reference, so there is nothing to verify it
         // against): the DCT-II as a fixed-point map of 23 fractional bits, evaluated exactly on the matrix units; the
         // quotient by Q in fp32 -- two integer -> float conversions, one fma, one product, each rounded to nearest even --
-        // and the nearest integer of that by the 1.5 * 2^23 addition (ties to even).  The checker (oracle/jpeg_oracle.c,
-        // std_block) performs the same operations in the same order.
+        // and the nearest integer of that by the 1.5 * 2^23 addition (ties to even).  The test suite's checker restates
+        // the same operations in the same order.
 #pragma unroll
         for (int r = 0; r < 4; ++r) qb[r] = __float_as_uint(aa[r]);  // 0x4B400000 + q
         return;
