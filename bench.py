@@ -501,8 +501,17 @@ def worker(args):
             # instruction holds it for 2 cycles: peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 wave-instructions/s.
             peak = 256 * 4 * 2.4e9 / 2 / 1e12
             rate = valu * frames_per_launch / t_launch / 1e12
+            # The same rate priced at what the kernel's instruction mix costs at its two waves per SIMD on this chip
+            # (tools/microbench/valu_issue.hip, profiles/r03_e_valu_issue_microbench.txt: 2.9 SIMD cycles for plain
+            # add/logic/shift, 3.6 with an SGPR source / conversions, 3.9 for integer multiply, permute and three-operand
+            # forms; ~3.6 for this mix) instead of the 2 cycles of the SIMD-32 model.
+            mix_cycles = 3.6
             line["valu_issue"] = {"achieved": round(rate, 4), "peak": round(peak, 4), "unit": "T wave-instructions/s",
-                                  "frac": round(rate / peak, 4), "insts_per_frame": valu, "source": traffic_src}
+                                  "frac": round(rate / peak, 4), "insts_per_frame": valu, "source": traffic_src,
+                                  "measured_cost_model": {"simd_cycles_per_instruction": mix_cycles, "waves_per_simd": 2,
+                                                          "peak": round(peak * 2 / mix_cycles, 4),
+                                                          "frac": round(rate / (peak * 2 / mix_cycles), 4),
+                                                          "source": "profiles/r03_e_valu_issue_microbench.txt"}}
 
     # ---- secondary measurements (rank 0, after the region; none of them is `value`) ---------------------
     if rank == 0 and not args.quick:

@@ -60,9 +60,12 @@ __device__ __forceinline__ uint32_t div31250(uint32_t s) { return mulhi24(s, 879
 
 template <bool STD>
 __device__ __forceinline__ uint32_t csc_int(int chan, uint32_t r, uint32_t g, uint32_t b) {
+    if constexpr (STD) {  // 15-bit fixed point (jpeg_tables.h); + 128 << 15 keeps the chroma numerator positive
+        const int s = kStdCsc[chan][0] * (int)r + kStdCsc[chan][1] * (int)g + kStdCsc[chan][2] * (int)b;
+        return (uint32_t)(s + (chan == 0 ? 16384 : 16383 + (128 << 15))) >> 15;
+    }
     if (chan == 0) {
         uint32_t s = 299u * r + 587u * g + 114u * b;  // <= 255000
-        if constexpr (STD) return div1000(s + 500u);
         uint32_t y = div1000(s);
         if (s == __umul24(y, 1000u)) y = csc1(r, g, b, 0.299, 0.587, 0.114, 0.0);
         return y;
@@ -70,10 +73,6 @@ __device__ __forceinline__ uint32_t csc_int(int chan, uint32_t r, uint32_t g, ui
         // numerators divided by 32 (exact: every constant and 128e6 are multiples of 32)
         const uint32_t s = chan == 1 ? 4000000u + 15625u * b - 5273u * r - 10352u * g
                                      : 4000000u + 15625u * r - 13084u * g - 2541u * b;
-        if constexpr (STD) {
-            const uint32_t v = div31250(s + 15625u);
-            return v > 255u ? 255u : v;
-        }
         return div31250(s);
     }
 }
@@ -132,9 +131,15 @@ template <bool STD, bool NOTIE = false>
 __device__ __forceinline__ uint32_t csc_packed(int chan, uint32_t rg, uint32_t b) {
     typedef short v2s __attribute__((ext_vector_type(2)));
     const v2s RG = __builtin_bit_cast(v2s, rg);
+    if constexpr (STD) {  // the same integers as csc_int<true>
+        const v2s K = chan == 0 ? v2s{(short)kStdCsc[0][0], (short)kStdCsc[0][1]}
+                                : (chan == 1 ? v2s{(short)kStdCsc[1][0], (short)kStdCsc[1][1]} : v2s{(short)kStdCsc[2][0], (short)kStdCsc[2][1]});
+        const int kb = chan == 0 ? kStdCsc[0][2] : (chan == 1 ? kStdCsc[1][2] : kStdCsc[2][2]);
+        const int s = __builtin_amdgcn_sdot2(RG, K, kb * (int)b + (chan == 0 ? 16384 : 16383 + (128 << 15)), false);
+        return (uint32_t)s >> 15;
+    }
     if (chan == 0) {
         const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, v2s{299, 587}, (int)(114u * b), false);
-        if constexpr (STD) return div1000(s + 500u);  // s <= 255000
         uint32_t y = div1000(s);
         if constexpr (!NOTIE)
             if (s == __umul24(y, 1000u)) y = csc1(rg & 0xffffu, rg >> 16, b, 0.299, 0.587, 0.114, 0.0);
@@ -143,10 +148,6 @@ __device__ __forceinline__ uint32_t csc_packed(int chan, uint32_t rg, uint32_t b
         const int kb = chan == 1 ? 15625 : -2541;
         const v2s K = chan == 1 ? v2s{-5273, -10352} : v2s{15625, -13084};
         const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, K, 4000000 + kb * (int)b, false);  // (128e6 + ...) / 32
-        if constexpr (STD) {  // s < 4000000 + 15625 * 255 < 8e6
-            const uint32_t v = div31250(s + 15625u);
-            return v > 255u ? 255u : v;
-        }
         return div31250(s);
     }
 }
@@ -232,7 +233,9 @@ __device__ __forceinline__ void generic_rowpair(const uint8_t* __restrict__ f, c
     }
 }
 
-// ---- 4:2:0 standard mode: one chroma sample = rounded mean of the 2x2 converted samples ----
+// ---- 4:2:0 standard mode: one chroma sample = the linear form box-filtered over the 2x2 quad, rounded once ----
+// (jpeg_tables.h: kStdCsc420).  VALU forms: edge MCUs, and the whole-tile form the matrix-unit path replaced (kept for
+// A/B builds, -DMI355_STD_CSC_VALU).
 // Raw RGB of pixel rows row0, row0+1 of MCU (mx,my): 2 x 48 bytes as twelve 8-byte loads (fast
 // path: every MCU of the wave interior, W % 8 == 0, base 8-aligned).
 __device__ __forceinline__ void load_raw_mcu_rows(const uint8_t* __restrict__ f, const Geom& g, uint32_t mx,
@@ -249,13 +252,17 @@ __device__ __forceinline__ void load_raw_mcu_rows(const uint8_t* __restrict__ f,
         }
     }
 }
-// One row of 8 chroma samples of channel CHAN from two pixel rows of 16, packed 4 per dword.
+__device__ __forceinline__ int std_lin420(int cc, uint32_t r, uint32_t g, uint32_t b) {
+    return kStdCsc420[cc][0] * (int)r + kStdCsc420[cc][1] * (int)g + kStdCsc420[cc][2] * (int)b;
+}
+// One row of 8 chroma samples of channel CHAN from two pixel rows of 16, packed 4 per dword (unsigned bytes).
 template <int CHAN>
 __device__ __forceinline__ void convert_chroma420_row(const uint32_t (&w)[24], uint32_t (&pk2)[2]) {
+    typedef short v2s __attribute__((ext_vector_type(2)));
     uint32_t m[8];
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
-        uint32_t sum = 2u;
+        int sum = 32767 + (128 << 16);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -265,15 +272,16 @@ __device__ __forceinline__ void convert_chroma420_row(const uint32_t (&w)[24], u
                 const uint32_t lo = w[r * 12 + i], hi = w[r * 12 + (i < 11 ? i + 1 : i)];
                 const uint32_t rg = __builtin_amdgcn_perm(hi, lo, (uint32_t)k | (kZ << 8) | ((uint32_t)(k + 1) << 16) | (kZ << 24));
                 const uint32_t b = (w[r * 12 + ((o + 2) >> 2)] >> (8 * ((o + 2) & 3))) & 255u;
-                sum += csc_packed<true>(CHAN, rg, b);
+                sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, rg), v2s{(short)kStdCsc420[CHAN - 1][0], (short)kStdCsc420[CHAN - 1][1]},
+                                             kStdCsc420[CHAN - 1][2] * (int)b + sum, false);
             }
-        m[x] = sum >> 2;
+        m[x] = (uint32_t)sum >> 16;
     }
     pk2[0] = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
     pk2[1] = m[4] | (m[5] << 8) | (m[6] << 16) | (m[7] << 24);
 }
-// Edge MCUs: one chroma sample at a time, every contributing pixel mirrored on its own
-// (the checker pads the converted image, then averages).
+// Edge MCUs: one chroma sample at a time, every contributing pixel mirrored on its own (the checker pads the RGB image,
+// then filters).
 __device__ __forceinline__ void generic_chroma420(const uint8_t* __restrict__ f, const Geom& g, int chan,
                                                   uint32_t mx, uint32_t my, uint32_t gq, uint32_t (&pk)[4]) {
 #pragma unroll 1
@@ -283,13 +291,109 @@ __device__ __forceinline__ void generic_chroma420(const uint8_t* __restrict__ f,
         for (int j = 0; j < 4; ++j) {
             const int sidx = i * 4 + j;  // 0..15 within the chroma row pair 2gq, 2gq+1
             const uint32_t px = mx * 16 + 2 * (sidx & 7), py = my * 16 + 2 * (gq * 2 + (sidx >> 3));
-            const uint32_t sum = sample_generic_int<true>(f, g, chan, false, px, py) +
-                                 sample_generic_int<true>(f, g, chan, false, px + 1, py) +
-                                 sample_generic_int<true>(f, g, chan, false, px, py + 1) +
-                                 sample_generic_int<true>(f, g, chan, false, px + 1, py + 1) + 2u;
-            v |= (sum >> 2) << (8 * j);
+            int sum = 32767 + (128 << 16);
+#pragma unroll 1
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t x = px + (d & 1), y = py + (d >> 1);
+                const uint32_t sx = x < g.W ? x : 2 * g.W - 1 - x, sy = y < g.H ? y : 2 * g.H - 1 - y;
+                const uint8_t* p = f + ((size_t)sy * g.W + sx) * 3;
+                sum += std_lin420(chan - 1, p[0], p[1], p[2]);
+            }
+            v |= ((uint32_t)sum >> 16) << (8 * j);
         }
         pk[i] = v;
+    }
+}
+
+// ---- standard mode: the colour conversion on the matrix units (whole tiles inside the image) ----
+// B operand = raw RGB bytes ^ 0x80 (x - 128 as int8), 16 consecutive bytes per lane; A = the block-diagonal fragment sets
+// of jpeg_tables.h / mi355_jpeg.cpp (upload_csc_frag): lane (n, gq) receives four outputs computed from its own bytes.
+// Coefficients are two balanced base-256 digits, so an output is (acc1 << 8) + acc0, exact in int32.  The rounding constant
+// travels in the accumulator input; because every coefficient row sums to a power of two (luma) or to zero (chroma), x - 128
+// in place of x changes nothing but the level shift the transform wants anyway: the result byte IS sample - 128.
+struct __attribute__((packed, aligned(8))) RawChunk {
+    uint32_t w[4];
+};
+__device__ __forceinline__ v4i chunk_b(const RawChunk& c) {
+    return v4i{(int)(c.w[0] ^ 0x80808080u), (int)(c.w[1] ^ 0x80808080u), (int)(c.w[2] ^ 0x80808080u), (int)(c.w[3] ^ 0x80808080u)};
+}
+__device__ __forceinline__ v4i splat4(int v) { return v4i{v, v, v, v}; }
+// byte 2 of each of four int32 -> one dword, in order
+__device__ __forceinline__ uint32_t pack_byte2(const v4i& s) {
+    const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)s[1], (uint32_t)s[0], 0x0c0c0602u);
+    const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)s[3], (uint32_t)s[2], 0x06020c0cu);
+    return p01 | p23;
+}
+__device__ __forceinline__ void load_csc_fragments(const ScreenParams& sp, uint32_t lane, int first_set, int n, v4i (&F)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < n) {
+            const uint4 t = sp.csc_frag[(first_set + i) * 64 + lane];
+            F[i] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+        }
+}
+// Rows 2gq, 2gq+1 of block (bx, by) as four chunks: [2r + h] = bytes 8h .. 8h+15 of row r (the two chunks of a row overlap
+// by 8 bytes; the fragments of half 1 ignore the first four bytes of theirs).
+__device__ __forceinline__ void load_std_rowpair(const uint8_t* __restrict__ f, const Geom& g, uint32_t bx, uint32_t by,
+                                                 uint32_t gq, RawChunk (&X)[6]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t off = (__umul24(by * 8 + gq * 2 + r, g.W) + bx * 8) * 3u;  // see load_raw_rowpair
+        X[2 * r] = *reinterpret_cast<const RawChunk*>(f + off);
+        X[2 * r + 1] = *reinterpret_cast<const RawChunk*>(f + off + 8);
+    }
+}
+// 16 samples - 128 of one channel (the fragments say which) from the row pair, packed 4 per dword in sample order.
+// Scale: coefficients x 2^15; the low digit is accumulated TWICE and the high one shifted by 9, which puts the binary point
+// at bit 16 -- the sample is byte 2 -- for two idle matrix instructions instead of sixteen shifts.
+// F = [half][digit].  The rounding constant -- 32768 for luma (half), 32766 for chroma (2 * (half - 1)) -- enters as
+// INLINE constants of the accumulator inputs (no registers): 64 << 9 through the high digit, 0 or -2 through the low one.
+template <bool CHROMA>
+__device__ __forceinline__ void std_rowpair_mfma(const RawChunk (&X)[6], const v4i (&F)[8], uint32_t (&pk)[4]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const v4i b = chunk_b(X[2 * r + h]);
+            v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[2 * h], b, splat4(CHROMA ? -2 : 0), 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[2 * h], b, a0, 0, 0, 0);
+            const v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[2 * h + 1], b, splat4(64), 0, 0, 0);
+            v4i sv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[i] = (a1[i] << 9) + a0[i];
+            pk[2 * r + h] = pack_byte2(sv);
+        }
+}
+// Pixel rows row0, row0+1 of MCU (mx, my): 2 x 48 bytes as [3r + c] = bytes 16c .. 16c+15 of row r.
+__device__ __forceinline__ void load_std_mcu_rows(const uint8_t* __restrict__ f, const Geom& g, uint32_t mx, uint32_t my,
+                                                  uint32_t row0, RawChunk (&X)[6]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t off = (__umul24(my * 16 + row0 + r, g.W) + mx * 16) * 3u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) X[3 * r + c] = *reinterpret_cast<const RawChunk*>(f + off + 16 * c);
+    }
+}
+// One row of 8 chroma samples - 128 from two pixel rows of 16 (coefficients c / 4 x 2^16: byte 2 again).
+// F = [pattern][digit] (patterns: upload_csc_frag); the four products of a sample group chain through the accumulator.
+__device__ __forceinline__ void std_chroma420_mfma(const RawChunk (&X)[6], const v4i (&F)[8], uint32_t (&pk2)[2]) {
+    v4i b[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = chunk_b(X[i]);
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        v4i a0 = splat4(32767), a1 = splat4(0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {  // chunk g2 + k with pattern 2 g2 + k
+                a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[2 * (2 * g2 + k)], b[3 * r + g2 + k], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[2 * (2 * g2 + k) + 1], b[3 * r + g2 + k], a1, 0, 0, 0);
+            }
+        v4i sv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sv[i] = (a1[i] << 8) + a0[i];
+        pk2[g2] = pack_byte2(sv);
     }
 }
 

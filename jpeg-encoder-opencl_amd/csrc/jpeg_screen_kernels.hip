@@ -64,6 +64,11 @@ __global__ void __launch_bounds__(256, 2)
     k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
     constexpr bool STD = MODE != 0, S420 = MODE == 2;
     constexpr uint32_t kPasses = S420 ? 6u : 3u;
+#ifdef MI355_STD_CSC_VALU  // A/B builds: standard mode's colour conversion on the VALU, as before round 3
+    constexpr bool kCscMfma = false;
+#else
+    constexpr bool kCscMfma = STD;  // standard mode converts whole tiles on the matrix units (jpeg_screen_devfn.h)
+#endif
     __shared__ uint32_t s_tbuf_all[kEncWaves][kRowWords];          // zig-zag rows, int16 [position][unit] (jpeg_screen_devfn.h)
     __shared__ alignas(16) uint32_t s_slot_all[kEncWaves][(kSlotRows + 1) * 64];  // AC strings [word][lane] + dump row
     __shared__ uint32_t s_mask_all[kEncWaves][2][64];              // non-zero masks (lo, hi)
@@ -72,7 +77,8 @@ __global__ void __launch_bounds__(256, 2)
     __shared__ uint32_t s_lut2[2][kLut2Words];  // (value,run) symbol tables
     __shared__ uint32_t s_dc[2][16];      // DC tables
 
-    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
+    const uint32_t tid = threadIdx.x, wv = tid >> 6;
+    uint32_t lane = tid & 63, n = lane & 15, gq = lane >> 4;
     uint32_t* s_tbuf = s_tbuf_all[wv];
     uint32_t* s_slot = s_slot_all[wv];
     uint32_t* s_mlo = s_mask_all[wv][0];
@@ -203,9 +209,26 @@ __global__ void __launch_bounds__(256, 2)
         return ps;
     };
     uint32_t raw[12];  // raw RGB of the row pair to convert next (fast path)
+    RawChunk Xn[6];    // the same for the matrix-unit conversion: the next step's chunks (a row pair, or two pixel rows of an MCU)
+    v4i F[8];          // ... and the colour-conversion fragments of the pass they belong to
     auto request_first_rows = [&](const Pass& ps) {
         const bool chroma420 = S420 && ps.chan >= 4u;
-        if (ps.fast && !chroma420) load_raw_rowpair(rgb + (size_t)ps.frame * g.frame_stride, g, ps.bxs[0], ps.bys[0], gq, raw);
+        if (!ps.fast) return;
+        const uint8_t* pf = rgb + (size_t)ps.frame * g.frame_stride;
+        if constexpr (kCscMfma) {
+            // the pass's colour-conversion fragments travel with its first rows: requested before the walk of the pass in
+            // front, they do not queue behind that pass's string stores (vmcnt retires in issue order)
+            const uint32_t pcomp = S420 ? (ps.chan < 4u ? 0u : ps.chan - 3u) : ps.chan;
+            if (chroma420) {
+                load_csc_fragments(sp, lane, kCscRowpairSets + (int)(pcomp - 1u) * 8, 8, F);
+                load_std_mcu_rows(pf, g, ps.bxs[0], ps.bys[0], 4 * gq, Xn);
+            } else {
+                load_csc_fragments(sp, lane, (int)pcomp * 4, 4, F);
+                load_std_rowpair(pf, g, ps.bxs[0], ps.bys[0], gq, Xn);
+            }
+        } else {
+            if (!chroma420) load_raw_rowpair(pf, g, ps.bxs[0], ps.bys[0], gq, raw);
+        }
     };
     Pass cur{}, nxt{};
     if (pstart < pairs_total) {
@@ -214,6 +237,12 @@ __global__ void __launch_bounds__(256, 2)
     }
     for (uint32_t p = pstart; p < pairs_total; p += pstep) {
         STAMP(7);
+        if constexpr (kCscMfma && S420) {
+            // everything derived from the lane number is recomputed per pass instead of living in registers of its own: this
+            // kernel has to stay within 224 registers, or the tail kernels of the part in front cannot run beside it
+            asm volatile("" : "+v"(lane));
+            n = lane & 15u, gq = lane >> 4;
+        }
         const uint32_t frame = cur.frame, tile = cur.tile, chan = cur.chan;
         // `chan` is the pass; the colour component differs from it only in 4:2:0 (passes 0..3 = luma)
         const uint32_t comp = S420 ? (chan < 4u ? 0u : chan - 3u) : chan;
@@ -243,13 +272,34 @@ __global__ void __launch_bounds__(256, 2)
         s_mhi[lane] = 0;
         __builtin_amdgcn_wave_barrier();
 
+        const bool on_mfma = kCscMfma && fast;
         // raw RGB of unit-tile j+1 is fetched while unit-tile j is processed (that of unit-tile 0 was requested a pass ago)
         uint32_t dcsum = 0;  // sample sum of the block whose coefficient 0 this lane will form
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t bx = bxs[j], by = bys[j];
-            uint32_t pk[4];
-            if (chroma420) {
+            uint32_t pk[4];  // 16 samples; on_mfma: as sample - 128 (int8), else unsigned
+            if (on_mfma) {
+                if constexpr (kCscMfma) {
+                    if (chroma420) {
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {  // chroma row 2gq + half <- pixel rows 4gq + 2half, + 1
+                            // ONE buffer of six chunks: double buffering costs 24 more registers, and above 224 the tail
+                            // kernels of the part in front no longer fit beside two of these workgroups (-19 % in batches)
+                            uint32_t o[2];
+                            std_chroma420_mfma(Xn, F, o);
+                            pk[2 * half] = o[0], pk[2 * half + 1] = o[1];
+                            if (half == 0) load_std_mcu_rows(f, g, bx, by, 4 * gq + 2, Xn);
+                            else if (j < 3) load_std_mcu_rows(f, g, bxs[j + 1], bys[j + 1], 4 * gq, Xn);
+                        }
+                    } else {
+                        // (one buffer: the next row pair lands during the quantiser)
+                        if (comp) std_rowpair_mfma<true>(Xn, F, pk);
+                        else std_rowpair_mfma<false>(Xn, F, pk);
+                        if (j < 3) load_std_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, Xn);
+                    }
+                }
+            } else if (chroma420) {
                 if constexpr (S420) {  // rows 2gq, 2gq+1 of the MCU's 8x8 chroma block <- pixel rows 4gq .. 4gq+3
                     if (fast) {
 #pragma unroll 1
@@ -286,7 +336,7 @@ __global__ void __launch_bounds__(256, 2)
                 if (sp.samples && tile * 64 + 16 * j + n < g.N) {
 #pragma unroll
                     for (int sidx = 0; sidx < 16; ++sidx) {
-                        uint32_t v = (pk[sidx >> 2] >> (8 * (sidx & 3))) & 255u;
+                        uint32_t v = ((pk[sidx >> 2] ^ (on_mfma ? 0x80808080u : 0u)) >> (8 * (sidx & 3))) & 255u;
                         size_t px = (size_t)(by * 8 + gq * 2 + (sidx >> 3)) * g.W8 + bx * 8 + (sidx & 7);
                         sp.samples[((size_t)frame * g.W8 * g.H8 + px) * 3 + chan] = (uint8_t)v;
                     }
@@ -295,13 +345,22 @@ __global__ void __launch_bounds__(256, 2)
             STAMP(5);
             // sum of the block's 64 samples (for the exact DC): 16 in this lane, then over the 4 row-pair lanes
             uint32_t ssum = 0;
+            v4i B;
+            if (on_mfma) {  // signed bytes already: the sum of the unsigned samples is 16 * 128 more
+                int sg = 2048;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ssum = __builtin_amdgcn_sad_u8(pk[i], 0u, ssum);
+                for (int i = 0; i < 4; ++i) sg = __builtin_amdgcn_sdot4((int)pk[i], 0x01010101, sg, false);
+                ssum = (uint32_t)sg;
+                B = v4i{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ssum = __builtin_amdgcn_sad_u8(pk[i], 0u, ssum);
+                // level shift: sample - 128 as int8 == sample ^ 0x80
+                B = v4i{(int)(pk[0] ^ 0x80808080u), (int)(pk[1] ^ 0x80808080u), (int)(pk[2] ^ 0x80808080u),
+                        (int)(pk[3] ^ 0x80808080u)};
+            }
             ssum += __shfl_xor(ssum, 16);
             ssum += __shfl_xor(ssum, 32);
-            // level shift: sample - 128 as int8 == sample ^ 0x80
-            const v4i B = v4i{(int)(pk[0] ^ 0x80808080u), (int)(pk[1] ^ 0x80808080u),
-                              (int)(pk[2] ^ 0x80808080u), (int)(pk[3] ^ 0x80808080u)};
 
             // coefficient 0 is formed exactly after this loop, by the lane (n, gq == j) for unit 16j+n
             if (gq == (uint32_t)j) dcsum = ssum;

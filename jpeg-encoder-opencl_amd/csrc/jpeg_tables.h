@@ -58,4 +58,20 @@ constexpr double kScaleXX = 0x1p-2;                // neither
         {0.5, -0.418688, -0.081312, 128.0},          \
     }
 
+// Standard mode (not a behaviour of the reference): colour conversion DEFINED in 15-bit fixed point, libjpeg's form --
+//     Y  = ( 9798 R + 19235 G +  3735 B + 16384) >> 15
+//     Cb = ((-5529 R - 10855 G + 16384 B + 16383) >> 15) + 128      (arithmetic shift; "half - 1": 255.5 cannot become 256)
+//     Cr = ((16384 R - 13720 G -  2664 B + 16383) >> 15) + 128
+// every row sums exactly (2^15, 0, 0): nothing to clamp, greys stay grey, and with x' = x - 128 the same formulas give
+// the level-shifted samples without an offset term.  4:2:0 chroma: the same linear form box-filtered over the 2x2 quad
+// and rounded ONCE, coefficients c / 4 at 16 bits --
+//     Cb = ((sum_quad(-2765 R - 5427 G + 8192 B) + 32767) >> 16) + 128,  Cr = ((sum_quad(8192 R - 6860 G - 1332 B) + 32767) >> 16) + 128.
+constexpr int kStdCsc[3][3] = {{9798, 19235, 3735}, {-5529, -10855, 16384}, {16384, -13720, -2664}};
+constexpr int kStdCsc420[2][3] = {{-2765, -5427, 8192}, {8192, -6860, -1332}};
+// Fragment sets of that conversion for the matrix units (built by the host, mi355_jpeg.cpp: build_std_csc_fragments;
+// consumed by jpeg_screen_devfn.h: std_rowpair_mfma / std_chroma420_mfma).  Set index:
+//   row pairs (4:4:4 all channels, 4:2:0 luma): ((chan * 2 + half) * 2 + digit), 12 sets
+//   4:2:0 chroma: 12 + ((c * 4 + pattern) * 2 + digit), c = 0 Cb / 1 Cr, 16 sets
+constexpr int kCscRowpairSets = 12, kCsc420Sets = 16, kCscSets = kCscRowpairSets + kCsc420Sets;
+
 }  // namespace mi355

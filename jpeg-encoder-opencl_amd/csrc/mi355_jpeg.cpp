@@ -340,6 +340,47 @@ int upload_afrag(mi355_jpeg_ctx* c) {
     return MI355_OK;
 }
 
+// MFMA A fragments of standard mode's colour conversion (jpeg_tables.h).  The B operand of v_mfma_i32_16x16x64_i8 is raw
+// RGB: lane (n, g) supplies 16 consecutive bytes (XOR 0x80 = x - 128) of ITS OWN rows as K chunk g, so the A matrix is
+// block diagonal -- output row 4g + r only reads K chunk g -- and lane (n, g) receives the four outputs r = 0..3 computed
+// from its own bytes: no data crosses lanes.  A set is the 4 x 16 matrix W[r][t] (digit of the coefficient that byte t of
+// the chunk contributes to output r), laid out as fragment lane (m, kq) = W[m & 3][.] if (m >> 2) == kq, else zero.
+// Coefficients are split into two balanced base-256 digits: c = 256 d1 + d0, d0 in -128..127.
+int upload_csc_frag(mi355_jpeg_ctx* c) {
+    std::vector<int8_t> h((size_t)kCscSets * 64 * 16, 0);
+    auto put = [&](int set, auto&& coef /* (r, t) -> coefficient or 0 */) {
+        for (int digit = 0; digit < 2; ++digit)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 15, kq = lane >> 4;
+                if ((m >> 2) != kq) continue;
+                for (int t = 0; t < 16; ++t) {
+                    const int cf = coef(m & 3, t);
+                    const int d0 = ((cf + 128) & 255) - 128, d1 = (cf - d0) / 256;
+                    h[((size_t)(set + digit) * 64 + lane) * 16 + t] = (int8_t)(digit ? d1 : d0);
+                }
+            }
+    };
+    // row pairs: the chunk of half 0 is bytes 0..15 of a block row (pixels 0..3 at chunk bytes 3r..3r+2), that of half 1 is
+    // bytes 8..23 (pixels 4..7 at chunk bytes 4 + 3r ..)
+    for (int chan = 0; chan < 3; ++chan)
+        for (int half = 0; half < 2; ++half)
+            put((chan * 2 + half) * 2, [&](int r, int t) {
+                const int o = t - (half ? 4 : 0) - 3 * r;
+                return o >= 0 && o < 3 ? kStdCsc[chan][o] : 0;
+            });
+    // 4:2:0 chroma: a pixel row of the MCU is 48 bytes = chunks 0, 1, 2; chroma sample cx reads row bytes 6cx..6cx+5 of two
+    // rows.  Patterns: 0 = (cx 0..3, chunk 0), 1 = (cx 0..3, chunk 1), 2 = (cx 4..7, chunk 1), 3 = (cx 4..7, chunk 2).
+    for (int cc = 0; cc < 2; ++cc)
+        for (int pat = 0; pat < 4; ++pat)
+            put(kCscRowpairSets + (cc * 4 + pat) * 2, [&](int r, int t) {
+                const int chunk = pat == 0 ? 0 : (pat == 3 ? 2 : 1), cx = (pat >= 2 ? 4 : 0) + r;
+                const int o = 16 * chunk + t - 6 * cx;  // byte within the sample's six
+                return o >= 0 && o < 6 ? kStdCsc420[cc][o % 3] : 0;
+            });
+    HIP_TRY(hipMemcpy(c->d_afrag + 2 * kAfragBytes / sizeof(uint4), h.data(), h.size(), hipMemcpyHostToDevice));
+    return MI355_OK;
+}
+
 int make_geom(uint32_t W, uint32_t H, uint32_t flags, const void* base, Geom* g) {
     if (W == 0 || H == 0 || W > 65535u || H > 65535u) return MI355_E_ARG;
     if ((flags & MI355_F_420) && !(flags & MI355_F_STANDARD)) return MI355_E_ARG;  // real 4:2:0 MCUs: standard mode only
@@ -417,6 +458,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.overflow_base = plan.grid * plan.region_words;
     const bool stdm = (g.flags & MI355_F_STANDARD) != 0;
     sp.afrag = c->d_afrag + (stdm ? kAfragBytes / sizeof(uint4) : 0);
+    sp.csc_frag = c->d_afrag + 2 * kAfragBytes / sizeof(uint4);
     sp.qconst = c->d_qconst;
     sp.qconst_f = c->d_qconst_f + (stdm ? 256 : 0);
     sp.qd = c->d_q;
@@ -831,7 +873,7 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
         hipMalloc((void**)&c->d_qzz, 128 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut, 2048 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_status, sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_afrag, 2 * kAfragBytes) != hipSuccess ||
+        hipMalloc((void**)&c->d_afrag, 2 * kAfragBytes + (size_t)kCscSets * 1024) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst_f, 512 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut2, 4 * 66 * 16 * sizeof(uint32_t)) != hipSuccess ||
@@ -842,6 +884,7 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     if (!e) e = hip_err(hipMemset(c->d_status, 0, sizeof(uint32_t)));
     if (!e) e = hip_err(hipMemset(c->d_counters, 0, 64 * sizeof(uint32_t)));
     if (!e) e = upload_afrag(c);
+    if (!e) e = upload_csc_frag(c);
     if (!e) e = upload_tables(c);
     if (!e) e = hip_err(hipDeviceSynchronize());  // every fill and table copy above has landed
     if (e) {

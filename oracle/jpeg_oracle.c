@@ -570,8 +570,35 @@ static void std_block(const int32_t p[64], const uint32_t *q, const uint8_t zz[6
     }
 }
 
-/* colour conversion, padding, (4:2:0: chroma means), exact fixed-point DCT + quantisation.
- * Returns the malloc'd zig-zag rows (layout: see orc_std_encode) or NULL for a refused size. */
+/* Standard-mode colour conversion: DEFINED as 15-bit fixed point, the form libjpeg's jccolor.c uses with 16 bits
+ * (Y = (c.RGB + half) >> bits; chroma with the "half - 1" constant so that 255.5 cannot round to 256; every row of
+ * coefficients sums to its exact total, so a grey pixel stays grey):
+ *     Y  = ( 9798 R + 19235 G +  3735 B + 16384) >> 15
+ *     Cb = ((-5529 R - 10855 G + 16384 B + 16383) >> 15) + 128         (arithmetic shift = floor)
+ *     Cr = ((16384 R - 13720 G -  2664 B + 16383) >> 15) + 128
+ * and 4:2:0 chroma as the box filter of the same linear form over the 2x2 quad, rounded ONCE (coefficients c/4 at 16 bits):
+ *     Cb = ((sum_quad(-2765 R - 5427 G + 8192 B) + 32767) >> 16) + 128
+ *     Cr = ((sum_quad( 8192 R - 6860 G - 1332 B) + 32767) >> 16) + 128
+ * The HIP path evaluates exactly these integers (on the matrix units where a tile lies inside the image). */
+static const int kStdY[3] = {9798, 19235, 3735};
+static const int kStdC[2][3] = {{-5529, -10855, 16384}, {16384, -13720, -2664}};
+static const int kStdC420[2][3] = {{-2765, -5427, 8192}, {8192, -6860, -1332}};
+static int32_t std_floor_shift(int64_t v, int bits) { /* floor(v / 2^bits) without relying on >> of negatives */
+    const int64_t d = (int64_t)1 << bits;
+    return (int32_t)(v >= 0 ? v / d : -((-v + d - 1) / d));
+}
+void orc_std_csc(const uint8_t *rgb, size_t n, uint8_t *ycc) { /* per-pixel form (4:4:4 and every luma sample) */
+    for (size_t i = 0; i < n; ++i) {
+        const int r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
+        ycc[3 * i] = (uint8_t)std_floor_shift((int64_t)kStdY[0] * r + kStdY[1] * g + kStdY[2] * b + 16384, 15);
+        for (int c = 0; c < 2; ++c)
+            ycc[3 * i + 1 + c] =
+                (uint8_t)(std_floor_shift((int64_t)kStdC[c][0] * r + kStdC[c][1] * g + kStdC[c][2] * b + 16383, 15) + 128);
+    }
+}
+
+/* mirror padding of the RGB image, colour conversion (4:2:0: chroma straight from the padded RGB quads), fixed-point DCT +
+ * quantisation.  Returns the malloc'd zig-zag rows (layout: see orc_std_encode) or NULL for a refused size. */
 static int32_t *std_transform(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
                               const uint32_t qchrom[64], const int64_t *dct, int subsample, size_t *Wp_out,
                               size_t *Hp_out, size_t *M_out) {
@@ -581,19 +608,10 @@ static int32_t *std_transform(const uint8_t *rgb, size_t W, size_t H, const uint
     const size_t M = (Wp / A) * (Hp / A);            /* MCUs */
     const size_t units = subsample ? 6 * M : 3 * M;  /* 8x8 blocks in the scan */
     *Wp_out = Wp, *Hp_out = Hp, *M_out = M;
-    uint8_t *img = (uint8_t *)malloc(W * H * 3), *pad = (uint8_t *)malloc(Wp * Hp * 3);
+    uint8_t *prgb = (uint8_t *)malloc(Wp * Hp * 3), *pad = (uint8_t *)malloc(Wp * Hp * 3);
     int32_t *zig = (int32_t *)malloc(units * 64 * sizeof(int32_t));
-    for (size_t i = 0; i < W * H; ++i) {
-        long r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
-        long y = (299 * r + 587 * g + 114 * b + 500) / 1000;
-        long cb = (128000000L + 500000 * b - 168736 * r - 331264 * g + 500000) / 1000000;
-        long cr = (128000000L + 500000 * r - 418688 * g - 81312 * b + 500000) / 1000000;
-        img[3 * i] = (uint8_t)(y > 255 ? 255 : y);
-        img[3 * i + 1] = (uint8_t)(cb > 255 ? 255 : cb);
-        img[3 * i + 2] = (uint8_t)(cr > 255 ? 255 : cr);
-    }
-    orc_pad(img, W, H, pad, Wp, Hp);
-    free(img);
+    orc_pad(rgb, W, H, prgb, Wp, Hp); /* pixel-wise conversion commutes with mirroring */
+    orc_std_csc(prgb, Wp * Hp, pad);
     uint8_t zz[64];
     orc_zigzag_order(zz);
     int32_t *dig = (int32_t *)malloc(3 * 4096 * sizeof(int32_t));
@@ -622,18 +640,23 @@ static int32_t *std_transform(const uint8_t *rgb, size_t W, size_t H, const uint
                     std_block(p, qlum, zz, dig, zig + (4 * mcu + k) * 64);
                 }
                 for (int c = 1; c < 3; ++c) {
-                    /* 2x2 mean of the converted samples, rounded to nearest (ties up) */
+                    /* box filter of the linear form over the 2x2 quad of (padded) RGB pixels, rounded once */
                     for (int s = 0; s < 64; ++s) {
                         const size_t x = mx * 16 + 2 * (s % 8), y = my * 16 + 2 * (s / 8);
-                        const int sum = pad[3 * (y * Wp + x) + c] + pad[3 * (y * Wp + x + 1) + c] +
-                                        pad[3 * ((y + 1) * Wp + x) + c] + pad[3 * ((y + 1) * Wp + x + 1) + c];
-                        p[s] = ((sum + 2) >> 2) - 128;
+                        int64_t acc = 32767;
+                        for (int dy = 0; dy < 2; ++dy)
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const uint8_t *px = prgb + 3 * ((y + dy) * Wp + x + dx);
+                                acc += (int64_t)kStdC420[c - 1][0] * px[0] + kStdC420[c - 1][1] * px[1] + kStdC420[c - 1][2] * px[2];
+                            }
+                        p[s] = std_floor_shift(acc, 16); /* = Cb - 128 */
                     }
                     std_block(p, qchrom, zz, dig, zig + ((size_t)(3 + c) * M + mcu) * 64);
                 }
             }
     }
     free(pad);
+    free(prgb);
     free(dig);
     return zig;
 }

@@ -102,9 +102,9 @@ int orc_entropy(const int32_t *zigzag, size_t n_blocks, uint8_t **bits, size_t *
  * NOT a behaviour of the reference (parity unpinned by it): a decodable baseline
  * JPEG, 4:4:4, defined entirely in integer arithmetic so that the GPU path and
  * this checker agree bit for bit:
- *   samples  Y  = min(255, (299R+587G+114B+500)/1000), Cb/Cr likewise with the
- *            1e6-scaled constants (round to nearest instead of the reference's
- *            truncation), mirror padding as in strict mode;
+ *   samples  15-bit fixed-point colour conversion in libjpeg's form (orc_std_csc:
+ *            Y = (9798R+19235G+3735B+16384)>>15, Cb/Cr likewise with the "half - 1"
+ *            constant; rows sum exactly, nothing to clamp), mirror padding as in strict mode;
  *   DCT      q[R] = round-half-away( sum_s dct[R][s]*(smp[s]-128) / (Q*2^39) ),
  *            dct = the true DCT-II rounded to 2^-39, rows in zig-zag order
  *            (tests/golden/std_dct_q39.i64, tools/gen_screen_tables.py);
@@ -113,10 +113,13 @@ int orc_entropy(const int32_t *zigzag, size_t n_blocks, uint8_t **bits, size_t *
  * keep: ORC_KEEP_ZIGZAG / ORC_KEEP_UNIT_BITS.
  *   subsample 0: 4:4:4, one Y, Cb, Cr block per 8x8 MCU; zigzag rows chan*M + block.
  *   subsample 1: 4:2:0, 16x16 MCUs (Y00 Y01 Y10 Y11 Cb Cr), image mirror-padded to multiples of 16,
- *            chroma = (sum of the 2x2 converted samples + 2) >> 2; zigzag rows: luma 4*mcu + k,
+ *            chroma = the same linear form box-filtered over the 2x2 quad of padded RGB pixels and rounded once
+ *            (coefficients c/4 at 16 bits, see orc_std_csc's comment); zigzag rows: luma 4*mcu + k,
  *            then Cb at 4M + mcu, Cr at 5M + mcu; n_blocks = M (MCUs); unit_bits in scan order. */
 int orc_std_encode(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],
                    const uint32_t qchrom[64], const int64_t *dct, int subsample, int keep, orc_result *out);
+/* the per-pixel colour conversion of standard mode: n RGB pixels -> n YCbCr pixels */
+void orc_std_csc(const uint8_t *rgb, size_t n, uint8_t *ycc);
 /* The whole file of standard mode WITH restart markers (DRI = interval MCUs): every interval starts
  * from zero DC predictors, is padded to a byte with 1s and, except the last, followed by RSTm. */
 long orc_std_jfif_restart(const uint8_t *rgb, size_t W, size_t H, const uint32_t qlum[64],

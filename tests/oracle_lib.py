@@ -59,6 +59,8 @@ def oracle():
         L.orc_std_encode.restype = C.c_int
         L.orc_std_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_int, C.POINTER(OrcResult)]
+        L.orc_std_csc.restype = None
+        L.orc_std_csc.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_std_jfif_restart.restype = C.c_long
         L.orc_std_jfif_restart.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_uint, C.c_void_p, C.c_size_t]
@@ -212,6 +214,38 @@ def oracle_entropy(zigzag):
 def std_dct_table():
     """The fixed-point true-DCT table that DEFINES standard mode (tests/golden/std_dct_q39.i64)."""
     return np.fromfile(os.path.join(ROOT, "tests", "golden", "std_dct_q39.i64"), "<i8").reshape(64, 64)
+
+
+STD_Y = (9798, 19235, 3735)                                     # x 2^-15, sum 2^15
+STD_C = ((-5529, -10855, 16384), (16384, -13720, -2664))        # Cb, Cr x 2^-15, each row sums to 0
+STD_C420 = ((-2765, -5427, 8192), (8192, -6860, -1332))         # the same / 4 at 16 bits (4:2:0 box filter)
+
+
+def std_csc(rgb):
+    """numpy restatement of standard mode's per-pixel colour conversion (15-bit fixed point, libjpeg's form)."""
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    y = (STD_Y[0] * r + STD_Y[1] * g + STD_Y[2] * b + 16384) >> 15
+    cc = [((c[0] * r + c[1] * g + c[2] * b + 16383) >> 15) + 128 for c in STD_C]
+    return np.stack([y] + cc, -1)
+
+
+def std_chroma420(rgb):
+    """4:2:0 chroma of standard mode for an image whose sides are even: the box filter of the linear form over
+    each 2x2 quad, rounded once.  Returns (H/2, W/2, 2)."""
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    out = []
+    for c in STD_C420:
+        lin = c[0] * r + c[1] * g + c[2] * b
+        quad = lin[0::2, 0::2] + lin[0::2, 1::2] + lin[1::2, 0::2] + lin[1::2, 1::2]
+        out.append(((quad + 32767) >> 16) + 128)
+    return np.stack(out, -1)
+
+
+def oracle_std_csc(rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    out = np.empty_like(rgb)
+    oracle().orc_std_csc(rgb.ctypes.data, rgb.size // 3, out.ctypes.data)
+    return out
 
 
 def oracle_std_encode(rgb, qlum, qchrom, keep=0, subsample=0):

@@ -2,7 +2,8 @@
 reference -- parity unpinned by it.  The mode is defined by its arithmetic (the true DCT-II as a fixed-point
 map: tests/golden/std_dct_q39.i64, of which the top three base-256 digits = 23 fractional bits are used,
 evaluated exactly in integers; the quotient by Q in single precision, nearest integer with ties to even;
-round-to-nearest colour conversion), so the checker in oracle/ and the HIP path must agree bit for bit;
+colour conversion in 15-bit fixed point, libjpeg's form; 4:2:0 chroma as the box filter of that linear form, rounded
+once), so the checker in oracle/ and the HIP path must agree bit for bit;
 what ties it to the outside world is that libjpeg (PIL) decodes the files to the picture an independent
 JPEG encoder produces, and that the quantised values are within one of the exact quotient's rounding."""
 import io
@@ -97,6 +98,40 @@ def test_oracle_420_files_decode_like_an_independent_encoder(kind, quality):
     assert abs(psnr(ours, rgb) - psnr(theirs, rgb)) < 0.1
 
 
+def test_standard_colour_conversion_definition():
+    """The fixed-point colour conversion that defines standard mode: the C checker equals the numpy restatement on all
+    2^24 inputs, every value lies in 0..255 without clamping, greys stay grey, and it is within 1 of the correctly
+    rounded real-valued conversion everywhere (equal to it for >= 99 % of the inputs)."""
+    v = np.arange(1 << 24, dtype=np.uint32)
+    rgb = np.stack([v >> 16, (v >> 8) & 255, v & 255], -1).astype(np.uint8)
+    want = ol.std_csc(rgb)
+    assert want.min() >= 0 and want.max() <= 255
+    assert np.array_equal(ol.oracle_std_csc(rgb), want.astype(np.uint8))
+    grey = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 3, 1)
+    assert np.array_equal(ol.std_csc(grey), np.stack([grey[:, 0], np.full(256, 128), np.full(256, 128)], -1))
+    r, g, b = (rgb[..., i].astype(np.float64) for i in range(3))
+    real = np.stack([0.299 * r + 0.587 * g + 0.114 * b, 128 - 0.168736 * r - 0.331264 * g + 0.5 * b,
+                     128 + 0.5 * r - 0.418688 * g - 0.081312 * b], -1)
+    diff = np.abs(want - np.minimum(np.floor(real + 0.5), 255))
+    assert diff.max() <= 1 and (diff == 0).mean() > 0.99
+
+
+def test_standard_420_chroma_definition():
+    """4:2:0 chroma = the linear form box-filtered over the quad and rounded once: in 0..255 without clamping, and within
+    1 of the rounded mean of the four per-pixel chroma values."""
+    rng = np.random.default_rng(11)
+    rgb = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    rgb[:8, :8] = 0, 0, 255      # extremes of Cb ...
+    rgb[8:16, :8] = 255, 255, 0
+    rgb[16:24, :8] = 255, 0, 0   # ... and Cr
+    rgb[24:32, :8] = 0, 255, 255
+    got = ol.std_chroma420(rgb)
+    assert got.min() == 0 and got.max() == 255
+    pp = ol.std_csc(rgb)[..., 1:]
+    mean = (pp[0::2, 0::2] + pp[0::2, 1::2] + pp[1::2, 0::2] + pp[1::2, 1::2] + 2) >> 2
+    assert np.abs(got - mean).max() <= 1
+
+
 def test_chroma_numerators_divide_by_32_for_all_inputs():
     """The HIP colour conversion forms the chroma numerators divided by 32 (constants that fit the
     16-bit lanes of v_dot2): floor(x / 1e6) == floor((x / 32) / 31250) and the rounded variants, for
@@ -142,10 +177,7 @@ def test_oracle_standard_coefficients_against_float_dct():
     import scipy.fft
     rgb = smooth_frame(96, 64, 9)
     rgb[:32] = ol.lcg_frame(96, 32, 5)  # some noise blocks as well
-    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
-    ycc = np.stack([np.minimum(255, (299 * r + 587 * g + 114 * b + 500) // 1000),
-                    np.minimum(255, (128000000 + 500000 * b - 168736 * r - 331264 * g + 500000) // 1000000),
-                    np.minimum(255, (128000000 + 500000 * r - 418688 * g - 81312 * b + 500000) // 1000000)], -1)
+    ycc = ol.std_csc(rgb)
     zz = ol.zigzag_order()
     for q in (50, 90, 100):
         ql, qc = ol.quant_tables(q)
@@ -243,8 +275,7 @@ def test_checker_quantiser_is_within_one_of_the_exact_quotient():
         rgb = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
         o = ol.oracle_std_encode(rgb, ql, qc, KEEP)
         # luma plane as the checker converts it
-        r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
-        y = np.minimum((299 * r + 587 * g + 114 * b + 500) // 1000, 255) - 128
+        y = ol.std_csc(rgb)[..., 0] - 128
         zz = ol.zigzag_order()
         bad = 0
         for blk in range(64):
