@@ -275,29 +275,79 @@ __global__ void __launch_bounds__(256, 2)
         const bool on_mfma = kCscMfma && fast;
         // raw RGB of unit-tile j+1 is fetched while unit-tile j is processed (that of unit-tile 0 was requested a pass ago)
         uint32_t dcsum = 0;  // sample sum of the block whose coefficient 0 this lane will form
+        bool chroma_done = false;
+        if constexpr (kCscMfma && S420) {
+            if (on_mfma && chroma420) {
+                // 4:2:0 chroma pass on the matrix units.  A unit-tile is two conversion steps (chroma row 2gq + half <- pixel
+                // rows 4gq + 2 half, + 1: six chunks each) over ONE chunk buffer -- a second one costs 24 registers, and above
+                // 224 the tail kernels of the part in front no longer fit beside two of these workgroups (-19 % in batches).
+                // What hides the loads is the quantiser, cut in two: rows 0..31 of unit-tile j follow its second step, rows
+                // 32..63 follow the first step of unit-tile j + 1, so every request but the pass's second has half a
+                // quantiser between issue and use.
+                chroma_done = true;
+                auto quantise_half = [&](const v4i& Bv, int jj, int mt0) {  // row tiles mt0, mt0 + 1 of unit-tile jj
+                    bool amb = false;
+                    uint32_t qprev[4], w = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+                    for (int mt = mt0; mt < mt0 + 2; ++mt) {
+                        uint32_t qb[4];
+                        screen_quantise<STD>(A[mt], Bv, sp, &s_qf[ct][4 * mt + gq][0], ct, mt, gq, lane, qb, amb);
+                        i16a* row = tb16 + (16 * mt + 4 * gq) * 64 + row_unit_off(16 * jj + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) row[r * 64] = (int16_t)qb[r];
+                        if (mt & 1) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const uint32_t pr = __builtin_amdgcn_perm(qb[r], qprev[r], 0x05040100u);
+                                uint32_t fl;
+                                asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(fl) : "v"(pr));
+                                w |= fl << r;
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) qprev[r] = qb[r];
+                        }
+                    }
+                    if (mt0 == 0) atomicOr(&s_mlo[16 * jj + n], (w << (4 * gq)) & ~1u);
+                    else atomicOr(&s_mhi[16 * jj + n], w << (4 * gq));
+                };
+                v4i Bp = v4i{0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t pk[4];
+                    uint32_t o[2];
+                    std_chroma420_mfma(Xn, F, o);
+                    pk[0] = o[0], pk[1] = o[1];
+                    load_std_mcu_rows(f, g, bxs[j], bys[j], 4 * gq + 2, Xn);
+                    if (j > 0) quantise_half(Bp, j - 1, 2);
+                    std_chroma420_mfma(Xn, F, o);
+                    pk[2] = o[0], pk[3] = o[1];
+                    if (j < 3) load_std_mcu_rows(f, g, bxs[j + 1], bys[j + 1], 4 * gq, Xn);
+                    STAMP(5);
+                    int sg = 2048;  // signed bytes: the sum of the unsigned samples is 16 * 128 more
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sg = __builtin_amdgcn_sdot4((int)pk[i], 0x01010101, sg, false);
+                    uint32_t ssum = (uint32_t)sg;
+                    ssum += __shfl_xor(ssum, 16);
+                    ssum += __shfl_xor(ssum, 32);
+                    if (gq == (uint32_t)j) dcsum = ssum;
+                    Bp = v4i{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+                    quantise_half(Bp, j, 0);
+                    STAMP(6);
+                }
+                quantise_half(Bp, 3, 2);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4 && !chroma_done; ++j) {
             const uint32_t bx = bxs[j], by = bys[j];
             uint32_t pk[4];  // 16 samples; on_mfma: as sample - 128 (int8), else unsigned
             if (on_mfma) {
                 if constexpr (kCscMfma) {
-                    if (chroma420) {
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {  // chroma row 2gq + half <- pixel rows 4gq + 2half, + 1
-                            // ONE buffer of six chunks: double buffering costs 24 more registers, and above 224 the tail
-                            // kernels of the part in front no longer fit beside two of these workgroups (-19 % in batches)
-                            uint32_t o[2];
-                            std_chroma420_mfma(Xn, F, o);
-                            pk[2 * half] = o[0], pk[2 * half + 1] = o[1];
-                            if (half == 0) load_std_mcu_rows(f, g, bx, by, 4 * gq + 2, Xn);
-                            else if (j < 3) load_std_mcu_rows(f, g, bxs[j + 1], bys[j + 1], 4 * gq, Xn);
-                        }
-                    } else {
-                        // (one buffer: the next row pair lands during the quantiser)
-                        if (comp) std_rowpair_mfma<true>(Xn, F, pk);
-                        else std_rowpair_mfma<false>(Xn, F, pk);
-                        if (j < 3) load_std_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, Xn);
-                    }
+                    // (one buffer: the next row pair lands during the quantiser)
+                    if (comp) std_rowpair_mfma<true>(Xn, F, pk);
+                    else std_rowpair_mfma<false>(Xn, F, pk);
+                    if (j < 3) load_std_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, Xn);
                 }
             } else if (chroma420) {
                 if constexpr (S420) {  // rows 2gq, 2gq+1 of the MCU's 8x8 chroma block <- pixel rows 4gq .. 4gq+3
