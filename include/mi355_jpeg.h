@@ -54,13 +54,13 @@ enum mi355_jpeg_status {
                                 Set = reference behaviour; clear = "4:4:4 (no subsample)" build convention */
 #define MI355_F_STANDARD 2u  /* SURVEY §8 f1 -- NOT a behaviour of the reference: a decodable baseline JPEG.
                                 True 8x8 DCT-II (as a fixed-point map of 23 fractional bits evaluated exactly on the
-                                matrix units, quotient by Q in fp32: the mode is defined by that arithmetic), round-to-nearest colour
-                                conversion, 4:4:4 unless MI355_F_420 (MI355_F_CDS is ignored), Annex K code tables proper (without
+                                matrix units, quotient by Q in fp32: the mode is defined by that arithmetic), colour conversion in
+                                15-bit fixed point (libjpeg's form: (c.RGB + half) >> 15, rows summing exactly), 4:4:4 unless MI355_F_420 (MI355_F_CDS is ignored), Annex K code tables proper (without
                                 the seven 17-bit entries of huffman.hpp:92-98), EOB omitted after a non-zero
                                 coefficient 63.  Files from mi355_jpeg_encode_jfif decode in libjpeg/PIL. */
 #define MI355_F_420 4u       /* with MI355_F_STANDARD only (MI355_E_ARG otherwise): real 4:2:0 -- 16x16 MCUs of four
-                                luma blocks + one Cb + one Cr block (sampling 2x2,1x1,1x1 in SOF0), chroma = rounded
-                                mean of the 2x2 converted samples, image mirror-padded to multiples of 16.
+                                luma blocks + one Cb + one Cr block (sampling 2x2,1x1,1x1 in SOF0), chroma = the conversion's
+                                linear form box-filtered over the 2x2 quad, rounded once; image mirror-padded to multiples of 16.
                                 Coefficient probe row order: luma 4*mcu + k (scan order), Cb at 4M + mcu, Cr at
                                 5M + mcu, M = MCUs.  (The reference's "subsampling" keeps full-resolution planes and
                                 is MI355_F_CDS.) */

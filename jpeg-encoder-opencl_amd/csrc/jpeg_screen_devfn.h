@@ -234,8 +234,7 @@ __device__ __forceinline__ void generic_rowpair(const uint8_t* __restrict__ f, c
 }
 
 // ---- 4:2:0 standard mode: one chroma sample = the linear form box-filtered over the 2x2 quad, rounded once ----
-// (jpeg_tables.h: kStdCsc420).  VALU forms: edge MCUs, and the whole-tile form the matrix-unit path replaced (kept for
-// A/B builds, -DMI355_STD_CSC_VALU).
+// (jpeg_tables.h: kStdCsc420).
 // Raw RGB of pixel rows row0, row0+1 of MCU (mx,my): 2 x 48 bytes as twelve 8-byte loads (fast
 // path: every MCU of the wave interior, W % 8 == 0, base 8-aligned).
 __device__ __forceinline__ void load_raw_mcu_rows(const uint8_t* __restrict__ f, const Geom& g, uint32_t mx,
@@ -305,7 +304,7 @@ __device__ __forceinline__ void generic_chroma420(const uint8_t* __restrict__ f,
     }
 }
 
-// ---- standard mode: the colour conversion on the matrix units (whole tiles inside the image) ----
+// ---- standard 4:4:4: the colour conversion on the matrix units (whole tiles inside the image) ----
 // B operand = raw RGB bytes ^ 0x80 (x - 128 as int8), 16 consecutive bytes per lane; A = the block-diagonal fragment sets
 // of jpeg_tables.h / mi355_jpeg.cpp (upload_csc_frag): lane (n, gq) receives four outputs computed from its own bytes.
 // Coefficients are two balanced base-256 digits, so an output is (acc1 << 8) + acc0, exact in int32.  The rounding constant
@@ -324,18 +323,17 @@ __device__ __forceinline__ uint32_t pack_byte2(const v4i& s) {
     const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)s[3], (uint32_t)s[2], 0x06020c0cu);
     return p01 | p23;
 }
-__device__ __forceinline__ void load_csc_fragments(const ScreenParams& sp, uint32_t lane, int first_set, int n, v4i (&F)[8]) {
+__device__ __forceinline__ void load_csc_fragments(const ScreenParams& sp, uint32_t lane, int first_set, v4i (&F)[4]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (i < n) {
-            const uint4 t = sp.csc_frag[(first_set + i) * 64 + lane];
-            F[i] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
-        }
+    for (int i = 0; i < 4; ++i) {
+        const uint4 t = sp.csc_frag[(first_set + i) * 64 + lane];
+        F[i] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+    }
 }
 // Rows 2gq, 2gq+1 of block (bx, by) as four chunks: [2r + h] = bytes 8h .. 8h+15 of row r (the two chunks of a row overlap
 // by 8 bytes; the fragments of half 1 ignore the first four bytes of theirs).
 __device__ __forceinline__ void load_std_rowpair(const uint8_t* __restrict__ f, const Geom& g, uint32_t bx, uint32_t by,
-                                                 uint32_t gq, RawChunk (&X)[6]) {
+                                                 uint32_t gq, RawChunk (&X)[4]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const uint32_t off = (__umul24(by * 8 + gq * 2 + r, g.W) + bx * 8) * 3u;  // see load_raw_rowpair
@@ -349,7 +347,7 @@ __device__ __forceinline__ void load_std_rowpair(const uint8_t* __restrict__ f, 
 // F = [half][digit].  The rounding constant -- 32768 for luma (half), 32766 for chroma (2 * (half - 1)) -- enters as
 // INLINE constants of the accumulator inputs (no registers): 64 << 9 through the high digit, 0 or -2 through the low one.
 template <bool CHROMA>
-__device__ __forceinline__ void std_rowpair_mfma(const RawChunk (&X)[6], const v4i (&F)[8], uint32_t (&pk)[4]) {
+__device__ __forceinline__ void std_rowpair_mfma(const RawChunk (&X)[4], const v4i (&F)[4], uint32_t (&pk)[4]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -364,39 +362,6 @@ __device__ __forceinline__ void std_rowpair_mfma(const RawChunk (&X)[6], const v
             pk[2 * r + h] = pack_byte2(sv);
         }
 }
-// Pixel rows row0, row0+1 of MCU (mx, my): 2 x 48 bytes as [3r + c] = bytes 16c .. 16c+15 of row r.
-__device__ __forceinline__ void load_std_mcu_rows(const uint8_t* __restrict__ f, const Geom& g, uint32_t mx, uint32_t my,
-                                                  uint32_t row0, RawChunk (&X)[6]) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const uint32_t off = (__umul24(my * 16 + row0 + r, g.W) + mx * 16) * 3u;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) X[3 * r + c] = *reinterpret_cast<const RawChunk*>(f + off + 16 * c);
-    }
-}
-// One row of 8 chroma samples - 128 from two pixel rows of 16 (coefficients c / 4 x 2^16: byte 2 again).
-// F = [pattern][digit] (patterns: upload_csc_frag); the four products of a sample group chain through the accumulator.
-__device__ __forceinline__ void std_chroma420_mfma(const RawChunk (&X)[6], const v4i (&F)[8], uint32_t (&pk2)[2]) {
-    v4i b[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) b[i] = chunk_b(X[i]);
-#pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2) {
-        v4i a0 = splat4(32767), a1 = splat4(0);
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {  // chunk g2 + k with pattern 2 g2 + k
-                a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[2 * (2 * g2 + k)], b[3 * r + g2 + k], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[2 * (2 * g2 + k) + 1], b[3 * r + g2 + k], a1, 0, 0, 0);
-            }
-        v4i sv;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sv[i] = (a1[i] << 8) + a0[i];
-        pk2[g2] = pack_byte2(sv);
-    }
-}
-
 // ----------------------------------------------------------------------------
 // device-side parameter block
 // ----------------------------------------------------------------------------

@@ -64,10 +64,15 @@ __global__ void __launch_bounds__(256, 2)
     k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
     constexpr bool STD = MODE != 0, S420 = MODE == 2;
     constexpr uint32_t kPasses = S420 ? 6u : 3u;
-#ifdef MI355_STD_CSC_VALU  // A/B builds: standard mode's colour conversion on the VALU, as before round 3
+#ifdef MI355_STD_CSC_VALU  // A/B builds: standard 4:4:4's colour conversion on the VALU as well
     constexpr bool kCscMfma = false;
 #else
-    constexpr bool kCscMfma = STD;  // standard mode converts whole tiles on the matrix units (jpeg_screen_devfn.h)
+    // Standard 4:4:4 converts whole tiles on the matrix units (jpeg_screen_devfn.h: +4 %).  4:2:0 does not: the same
+    // scheme for its chroma passes was built and measured at -1.5 % (profiles/r03_f_*) -- a matrix
+    // instruction costs the issuing wave what 2.5 plain VALU instructions cost, the fixed-point form needs only four of
+    // those per pixel, and the fragments' registers push the kernel to the limit beyond which the tail kernels stop
+    // running beside it.
+    constexpr bool kCscMfma = MODE == 1;
 #endif
     __shared__ uint32_t s_tbuf_all[kEncWaves][kRowWords];          // zig-zag rows, int16 [position][unit] (jpeg_screen_devfn.h)
     __shared__ alignas(16) uint32_t s_slot_all[kEncWaves][(kSlotRows + 1) * 64];  // AC strings [word][lane] + dump row
@@ -77,8 +82,7 @@ __global__ void __launch_bounds__(256, 2)
     __shared__ uint32_t s_lut2[2][kLut2Words];  // (value,run) symbol tables
     __shared__ uint32_t s_dc[2][16];      // DC tables
 
-    const uint32_t tid = threadIdx.x, wv = tid >> 6;
-    uint32_t lane = tid & 63, n = lane & 15, gq = lane >> 4;
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
     uint32_t* s_tbuf = s_tbuf_all[wv];
     uint32_t* s_slot = s_slot_all[wv];
     uint32_t* s_mlo = s_mask_all[wv][0];
@@ -209,8 +213,8 @@ __global__ void __launch_bounds__(256, 2)
         return ps;
     };
     uint32_t raw[12];  // raw RGB of the row pair to convert next (fast path)
-    RawChunk Xn[6];    // the same for the matrix-unit conversion: the next step's chunks (a row pair, or two pixel rows of an MCU)
-    v4i F[8];          // ... and the colour-conversion fragments of the pass they belong to
+    RawChunk Xn[4];    // the same for the matrix-unit conversion (standard 4:4:4): the next row pair's four chunks
+    v4i F[4];          // ... and the colour-conversion fragments of the pass they belong to
     auto request_first_rows = [&](const Pass& ps) {
         const bool chroma420 = S420 && ps.chan >= 4u;
         if (!ps.fast) return;
@@ -218,14 +222,8 @@ __global__ void __launch_bounds__(256, 2)
         if constexpr (kCscMfma) {
             // the pass's colour-conversion fragments travel with its first rows: requested before the walk of the pass in
             // front, they do not queue behind that pass's string stores (vmcnt retires in issue order)
-            const uint32_t pcomp = S420 ? (ps.chan < 4u ? 0u : ps.chan - 3u) : ps.chan;
-            if (chroma420) {
-                load_csc_fragments(sp, lane, kCscRowpairSets + (int)(pcomp - 1u) * 8, 8, F);
-                load_std_mcu_rows(pf, g, ps.bxs[0], ps.bys[0], 4 * gq, Xn);
-            } else {
-                load_csc_fragments(sp, lane, (int)pcomp * 4, 4, F);
-                load_std_rowpair(pf, g, ps.bxs[0], ps.bys[0], gq, Xn);
-            }
+            load_csc_fragments(sp, lane, (int)ps.chan * 4, F);
+            load_std_rowpair(pf, g, ps.bxs[0], ps.bys[0], gq, Xn);
         } else {
             if (!chroma420) load_raw_rowpair(pf, g, ps.bxs[0], ps.bys[0], gq, raw);
         }
@@ -237,12 +235,6 @@ __global__ void __launch_bounds__(256, 2)
     }
     for (uint32_t p = pstart; p < pairs_total; p += pstep) {
         STAMP(7);
-        if constexpr (kCscMfma && S420) {
-            // everything derived from the lane number is recomputed per pass instead of living in registers of its own: this
-            // kernel has to stay within 224 registers, or the tail kernels of the part in front cannot run beside it
-            asm volatile("" : "+v"(lane));
-            n = lane & 15u, gq = lane >> 4;
-        }
         const uint32_t frame = cur.frame, tile = cur.tile, chan = cur.chan;
         // `chan` is the pass; the colour component differs from it only in 4:2:0 (passes 0..3 = luma)
         const uint32_t comp = S420 ? (chan < 4u ? 0u : chan - 3u) : chan;
@@ -275,71 +267,8 @@ __global__ void __launch_bounds__(256, 2)
         const bool on_mfma = kCscMfma && fast;
         // raw RGB of unit-tile j+1 is fetched while unit-tile j is processed (that of unit-tile 0 was requested a pass ago)
         uint32_t dcsum = 0;  // sample sum of the block whose coefficient 0 this lane will form
-        bool chroma_done = false;
-        if constexpr (kCscMfma && S420) {
-            if (on_mfma && chroma420) {
-                // 4:2:0 chroma pass on the matrix units.  A unit-tile is two conversion steps (chroma row 2gq + half <- pixel
-                // rows 4gq + 2 half, + 1: six chunks each) over ONE chunk buffer -- a second one costs 24 registers, and above
-                // 224 the tail kernels of the part in front no longer fit beside two of these workgroups (-19 % in batches).
-                // What hides the loads is the quantiser, cut in two: rows 0..31 of unit-tile j follow its second step, rows
-                // 32..63 follow the first step of unit-tile j + 1, so every request but the pass's second has half a
-                // quantiser between issue and use.
-                chroma_done = true;
-                auto quantise_half = [&](const v4i& Bv, int jj, int mt0) {  // row tiles mt0, mt0 + 1 of unit-tile jj
-                    bool amb = false;
-                    uint32_t qprev[4], w = 0;
 #pragma unroll
-                    for (int mt = mt0; mt < mt0 + 2; ++mt) {
-                        uint32_t qb[4];
-                        screen_quantise<STD>(A[mt], Bv, sp, &s_qf[ct][4 * mt + gq][0], ct, mt, gq, lane, qb, amb);
-                        i16a* row = tb16 + (16 * mt + 4 * gq) * 64 + row_unit_off(16 * jj + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) row[r * 64] = (int16_t)qb[r];
-                        if (mt & 1) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const uint32_t pr = __builtin_amdgcn_perm(qb[r], qprev[r], 0x05040100u);
-                                uint32_t fl;
-                                asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(fl) : "v"(pr));
-                                w |= fl << r;
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) qprev[r] = qb[r];
-                        }
-                    }
-                    if (mt0 == 0) atomicOr(&s_mlo[16 * jj + n], (w << (4 * gq)) & ~1u);
-                    else atomicOr(&s_mhi[16 * jj + n], w << (4 * gq));
-                };
-                v4i Bp = v4i{0, 0, 0, 0};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t pk[4];
-                    uint32_t o[2];
-                    std_chroma420_mfma(Xn, F, o);
-                    pk[0] = o[0], pk[1] = o[1];
-                    load_std_mcu_rows(f, g, bxs[j], bys[j], 4 * gq + 2, Xn);
-                    if (j > 0) quantise_half(Bp, j - 1, 2);
-                    std_chroma420_mfma(Xn, F, o);
-                    pk[2] = o[0], pk[3] = o[1];
-                    if (j < 3) load_std_mcu_rows(f, g, bxs[j + 1], bys[j + 1], 4 * gq, Xn);
-                    STAMP(5);
-                    int sg = 2048;  // signed bytes: the sum of the unsigned samples is 16 * 128 more
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sg = __builtin_amdgcn_sdot4((int)pk[i], 0x01010101, sg, false);
-                    uint32_t ssum = (uint32_t)sg;
-                    ssum += __shfl_xor(ssum, 16);
-                    ssum += __shfl_xor(ssum, 32);
-                    if (gq == (uint32_t)j) dcsum = ssum;
-                    Bp = v4i{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
-                    quantise_half(Bp, j, 0);
-                    STAMP(6);
-                }
-                quantise_half(Bp, 3, 2);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4 && !chroma_done; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const uint32_t bx = bxs[j], by = bys[j];
             uint32_t pk[4];  // 16 samples; on_mfma: as sample - 128 (int8), else unsigned
             if (on_mfma) {

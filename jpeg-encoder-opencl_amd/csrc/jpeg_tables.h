@@ -68,10 +68,8 @@ constexpr double kScaleXX = 0x1p-2;                // neither
 //     Cb = ((sum_quad(-2765 R - 5427 G + 8192 B) + 32767) >> 16) + 128,  Cr = ((sum_quad(8192 R - 6860 G - 1332 B) + 32767) >> 16) + 128.
 constexpr int kStdCsc[3][3] = {{9798, 19235, 3735}, {-5529, -10855, 16384}, {16384, -13720, -2664}};
 constexpr int kStdCsc420[2][3] = {{-2765, -5427, 8192}, {8192, -6860, -1332}};
-// Fragment sets of that conversion for the matrix units (built by the host, mi355_jpeg.cpp: build_std_csc_fragments;
-// consumed by jpeg_screen_devfn.h: std_rowpair_mfma / std_chroma420_mfma).  Set index:
-//   row pairs (4:4:4 all channels, 4:2:0 luma): ((chan * 2 + half) * 2 + digit), 12 sets
-//   4:2:0 chroma: 12 + ((c * 4 + pattern) * 2 + digit), c = 0 Cb / 1 Cr, 16 sets
-constexpr int kCscRowpairSets = 12, kCsc420Sets = 16, kCscSets = kCscRowpairSets + kCsc420Sets;
+// Fragment sets of the per-pixel conversion for the matrix units (built by the host, mi355_jpeg.cpp: upload_csc_frag;
+// consumed by jpeg_screen_devfn.h: std_rowpair_mfma): set ((chan * 2 + half) * 2 + digit), 12 sets.
+constexpr int kCscSets = 12;
 
 }  // namespace mi355

@@ -340,7 +340,7 @@ int upload_afrag(mi355_jpeg_ctx* c) {
     return MI355_OK;
 }
 
-// MFMA A fragments of standard mode's colour conversion (jpeg_tables.h).  The B operand of v_mfma_i32_16x16x64_i8 is raw
+// MFMA A fragments of standard mode's per-pixel colour conversion (jpeg_tables.h; used by the 4:4:4 kernel).  The B operand of v_mfma_i32_16x16x64_i8 is raw
 // RGB: lane (n, g) supplies 16 consecutive bytes (XOR 0x80 = x - 128) of ITS OWN rows as K chunk g, so the A matrix is
 // block diagonal -- output row 4g + r only reads K chunk g -- and lane (n, g) receives the four outputs r = 0..3 computed
 // from its own bytes: no data crosses lanes.  A set is the 4 x 16 matrix W[r][t] (digit of the coefficient that byte t of
@@ -367,15 +367,6 @@ int upload_csc_frag(mi355_jpeg_ctx* c) {
             put((chan * 2 + half) * 2, [&](int r, int t) {
                 const int o = t - (half ? 4 : 0) - 3 * r;
                 return o >= 0 && o < 3 ? kStdCsc[chan][o] : 0;
-            });
-    // 4:2:0 chroma: a pixel row of the MCU is 48 bytes = chunks 0, 1, 2; chroma sample cx reads row bytes 6cx..6cx+5 of two
-    // rows.  Patterns: 0 = (cx 0..3, chunk 0), 1 = (cx 0..3, chunk 1), 2 = (cx 4..7, chunk 1), 3 = (cx 4..7, chunk 2).
-    for (int cc = 0; cc < 2; ++cc)
-        for (int pat = 0; pat < 4; ++pat)
-            put(kCscRowpairSets + (cc * 4 + pat) * 2, [&](int r, int t) {
-                const int chunk = pat == 0 ? 0 : (pat == 3 ? 2 : 1), cx = (pat >= 2 ? 4 : 0) + r;
-                const int o = 16 * chunk + t - 6 * cx;  // byte within the sample's six
-                return o >= 0 && o < 6 ? kStdCsc420[cc][o % 3] : 0;
             });
     HIP_TRY(hipMemcpy(c->d_afrag + 2 * kAfragBytes / sizeof(uint4), h.data(), h.size(), hipMemcpyHostToDevice));
     return MI355_OK;
