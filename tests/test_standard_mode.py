@@ -213,10 +213,15 @@ def test_oracle_standard_eob_and_tables():
 @pytest.mark.gpu
 @pytest.mark.parametrize("W,H,q,kind", [(253, 254, 50, "fruit"), (640, 360, 50, "lcg"), (100, 37, 90, "lcg"),
                                         (1920, 1080, 75, "smooth"), (8, 8, 100, "lcg"), (333, 65, 25, "smooth"),
-                                        (512, 512, 100, "lcg")])
+                                        (512, 512, 100, "lcg"), (3840, 2160, 50, "lcg"), (2048, 72, 90, "extremes")])
 def test_gpu_standard_mode_equals_checker(jpeg, enc, W, H, q, kind):
     rgb = (ol.read_ppm(os.path.join(GOLD, "fruit.ppm")) if kind == "fruit"
            else ol.lcg_frame(W, H, 7) if kind == "lcg" else smooth_frame(W, H, 2))
+    if kind == "extremes":
+        # whole tiles inside the image (the colour conversion runs on the matrix units there) filled with the corner colours
+        # of the RGB cube and their neighbours: every extreme of Y, Cb and Cr, rounding at both ends of the range
+        corners = np.array([[r, g, b] for r in (0, 1, 254, 255) for g in (0, 1, 254, 255) for b in (0, 1, 254, 255)], np.uint8)
+        rgb = corners[np.random.default_rng(5).integers(0, len(corners), (H, W))]
     ql, qc = ol.quant_tables(q)
     enc.set_quant(ql, qc)
     o = ol.oracle_std_encode(rgb, ql, qc, KEEP)
