@@ -153,6 +153,7 @@ struct mi355_jpeg_ctx {
     uint32_t* d_lut2 = nullptr;     // [2 modes][2][66][16] whole AC symbols for |value| <= 31
     uint32_t* d_counters = nullptr; // [64] arena overflow-pool words, one per part in flight
     uint32_t max_sets = 0;          // MI355_JPEG_MAX_SETS (tests): upper limit of the workspace sets of a batch (0 = none)
+    uint32_t stagger = 0;           // MI355_JPEG_STAGGER (timing experiment, 0..64): later-dispatched workgroups start this many sleeps late
     unsigned long long* d_stats = nullptr;  // [0] second looks, [1] exact units (mi355_jpeg_screen_stats)
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
     uint8_t* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // scratch of the stage-by-stage entry points
@@ -441,10 +442,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     const size_t arena_words = plan.total_words;
     // the later-dispatched half of a launch that fills the device two workgroups per CU (see the kernel)
     sp.prio_from_wg = (c->n_cus > 0 && plan.grid / 4 == 2u * (uint32_t)c->n_cus) ? (uint32_t)c->n_cus : 0xFFFFFFFFu;
-    {
-        static const char* stg = getenv("MI355_JPEG_STAGGER");
-        sp.stagger = stg ? (uint32_t)atoi(stg) : 0u;
-    }
+    sp.stagger = c->stagger;
     sp.region_words = plan.region_words;
     sp.overflow_base = plan.grid * plan.region_words;
     const bool stdm = (g.flags & MI355_F_STANDARD) != 0;
@@ -751,6 +749,7 @@ struct Knobs {
     int encode_shape = 0;
     int pipeline = 0;
     uint32_t screen_waves = 0;  // 0: the device's default
+    uint32_t stagger = 0;
 };
 bool read_knobs(Knobs* k) {
     bool bad = false;
@@ -794,6 +793,7 @@ bool read_knobs(Knobs* k) {
         if (kv & 31) bad = true;
         else k->screen_waves = (uint32_t)kv;
     }
+    if (knob_uint("MI355_JPEG_STAGGER", 0, 64, &kv)) k->stagger = (uint32_t)kv;  // timing experiment: bounded, a sleep loop in the kernel
     return !bad;
 }
 
@@ -855,6 +855,7 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     c->tau_scale = kn.tau_scale;
     c->batch_parts = kn.batch_parts;
     c->max_sets = kn.max_sets;
+    c->stagger = kn.stagger;
     c->encode_shape = kn.encode_shape;
     c->pipeline = kn.pipeline;
     if (c->n_cus > 0) c->tile_wgs = (uint32_t)c->n_cus;
