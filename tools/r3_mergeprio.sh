@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box helper: k_merge at wave priority 3 (default) against 1 and 0 (it then takes only issue slots the block-encode
-# kernel of the next part leaves idle): bench --quick, interleaved
+# kernel of the next part leaves idle): bench --quick, interleaved.  The two libraries are builds with the s_setprio(3)
+# of k_merge (jpeg_screen_kernels.hip) edited to 1 and 0; that edit is not in the tree.
 set -e -o pipefail
 OUT=gpurun_out/$1; mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
