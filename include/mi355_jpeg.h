@@ -174,8 +174,7 @@ int mi355_jpeg_encode_scan(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, 
  * free device memory (at most 32 GB), otherwise as many as fit and parts take turns (a little slower:
  * a part then waits for the tail kernels of the part whose set it reuses); plus 12 bytes per tile (64
  * blocks) for every frame.  E.g. 128 4K frames at out_stride = 8 MiB: 8 parts, 5.7 GB; at out_stride =
- * mi355_jpeg_scan_bound (84 MB): 22 GB.  MI355_JPEG_PIPELINE=tile (strict / standard 4:4:4) needs 40
- * bytes per tile and nothing else. */
+ * mi355_jpeg_scan_bound (84 MB): 22 GB. */
 int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx *ctx, const void *d_rgb, uint32_t W, uint32_t H,
                                   uint32_t n_frames, uint32_t flags, void *d_out,
                                   size_t out_stride, uint64_t *d_bits, void *stream);

@@ -54,33 +54,10 @@ struct ScreenParams {
     unsigned long long* stamps;  // diagnostic build only (-DMI355_STAMPS): [wave][8] phase cycle sums
 };
 
-// Single-launch pipeline (jpeg_tile_kernels.hip): everything k_encode_tile needs besides the tables of `sp`.
-struct TileParams {
-    ScreenParams sp;               // tables, status, stats (meta / arena / counters / tile_bits / probe outputs unused)
-    unsigned long long* rec;       // [frames * tiles][8] hand-off granules: {last DC x3, scan state, carry word, -, -, -}
-    uint32_t* ticket;              // [frames] next tile of each frame to hand out (zeroed in stream order before every launch)
-    uint32_t epoch;                // 1..65535, changes with every launch (tag of this launch's granules)
-    uint32_t debug;                // reserved (diagnostics)
-    uint32_t* ovf;                 // [grid waves][54][64] overflow area for strings longer than their LDS slot
-    uint8_t* out;                  // frame f at out + f * out_stride
-    uint64_t out_stride;
-    uint64_t* frame_bits;          // [frames]; ~0 for a frame with an error (capacity, category)
-    uint64_t* tile_off;            // [frames][tiles + 1] bit offsets of the tiles (restart-interval stuffing reads them)
-};
-uint32_t tile_grid(const Geom& g, uint32_t n_frames, uint32_t max_wgs);
-size_t tile_ovf_words(uint32_t wgs);
-size_t tile_rec_granules(const Geom& g, uint32_t n_frames);
-hipError_t launch_encode_tile(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const TileParams& tp, uint32_t wgs,
-                              hipStream_t s);
-
 // number of persistent single-wave workgroups launch_screen_encode will use
 uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves);
 hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,
                                 bool probe, uint32_t grid_waves, hipStream_t s);
-// the same kernel at three waves per SIMD (jpeg_wide_kernels.hip: one 11-wave workgroup per CU; strict and standard 4:4:4)
-uint32_t wide_grid_waves(const Geom& g, uint32_t n_frames, uint32_t max_wgs);
-hipError_t launch_screen_encode_wide(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp, uint32_t grid_waves,
-                                     hipStream_t s);
 hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams& sp, hipStream_t s);
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,
                         const uint32_t* lut, const uint64_t* tile_off,

@@ -1,8 +1,5 @@
-// Device-side building blocks of the screened (integer-MFMA) pipeline, shared by its two kernel
-// files: jpeg_screen_kernels.hip (the four-launch pipeline: the library's DEFAULT, and the only one for
-// 4:2:0 standard mode) and jpeg_tile_kernels.hip (the single-launch pipeline: three waves per tile,
-// in-kernel scan and merge; opt-in with MI355_JPEG_PIPELINE=tile).  See jpeg_screen_kernels.hip's
-// header comment for why the screen is bit-exact.
+// Device-side building blocks of the screened (integer-MFMA) pipeline (jpeg_screen_kernels.hip).  See that
+// file's header comment for why the screen is bit-exact.
 #pragma once
 #include "jpeg_devfn.h"
 #include "jpeg_screen_tables.h"  // kScreenLimbs, kScreenFracBits (the tables themselves are uploaded by the host)
@@ -127,7 +124,7 @@ __device__ __forceinline__ void load_raw_rowpair(const uint8_t* __restrict__ f, 
 // and 128e6 are), so floor(x / 1e6) == floor((x / 32) / 31250) with constants that fit 16 bits:
 // 168736/32 = 5273, 331264/32 = 10352, 500000/32 = 15625, 418688/32 = 13084, 81312/32 = 2541.
 // Same results as csc_int for all 2^24 inputs (the exhaustive colour conversion tests run this one).
-template <bool STD, bool NOTIE = false>
+template <bool STD>
 __device__ __forceinline__ uint32_t csc_packed(int chan, uint32_t rg, uint32_t b) {
     typedef short v2s __attribute__((ext_vector_type(2)));
     const v2s RG = __builtin_bit_cast(v2s, rg);
@@ -141,8 +138,7 @@ __device__ __forceinline__ uint32_t csc_packed(int chan, uint32_t rg, uint32_t b
     if (chan == 0) {
         const uint32_t s = (uint32_t)__builtin_amdgcn_sdot2(RG, v2s{299, 587}, (int)(114u * b), false);
         uint32_t y = div1000(s);
-        if constexpr (!NOTIE)
-            if (s == __umul24(y, 1000u)) y = csc1(rg & 0xffffu, rg >> 16, b, 0.299, 0.587, 0.114, 0.0);
+        if (s == __umul24(y, 1000u)) y = csc1(rg & 0xffffu, rg >> 16, b, 0.299, 0.587, 0.114, 0.0);
         return y;
     } else {
         const int kb = chan == 1 ? 15625 : -2541;
@@ -159,7 +155,7 @@ __device__ __forceinline__ uint32_t csc_packed(int chan, uint32_t rg, uint32_t b
 // 7 % of the kernel (the branch machinery, not the rare fp64 code): so four pixels are converted branch-free with their
 // remainders (one v_mad_i32_i24 each), and ONE wave-uniform test per four pixels (taken 23 % of the time) guards the
 // per-pixel fix-ups.
-template <int CHAN, bool STD, bool NOTIE = false>
+template <int CHAN, bool STD>
 __device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool avg, uint32_t (&pk)[4]) {
     uint32_t val[2][8];
 #pragma unroll
@@ -185,10 +181,10 @@ __device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool av
                     rgs[xx] = rg, bs[xx] = b;
                     rem[xx] = s - __umul24(y, 1000u);
                 } else {
-                    val[r][x] = csc_packed<STD, NOTIE>(CHAN, rg, b);
+                    val[r][x] = csc_packed<STD>(CHAN, rg, b);
                 }
             }
-            if constexpr (CHAN == 0 && !STD && !NOTIE) {
+            if constexpr (CHAN == 0 && !STD) {
                 const uint32_t m01 = rem[0] < rem[1] ? rem[0] : rem[1], m23 = rem[2] < rem[3] ? rem[2] : rem[3];
                 if (wave_any((m01 < m23 ? m01 : m23) == 0u)) {
 #pragma unroll

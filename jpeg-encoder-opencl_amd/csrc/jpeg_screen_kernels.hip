@@ -31,14 +31,9 @@ namespace mi355 {
 constexpr uint32_t kEncWaves = 4;
 
 // An error in a unit also poisons its tile's bit total (bit 31, never reached by the sums): k_tile_scan then knows WHICH
-// frame failed.  (MI355_NO_POISON: A/B builds only.)
-#ifdef MI355_NO_POISON
-#define POISON_TILE() (void)0
-#define POISON_FT() (void)0
-#else
+// frame failed.
 #define POISON_TILE() atomicOr(&sp.tile_bits[(size_t)frame * g.tiles + tile], 0x80000000u)
 #define POISON_FT() atomicOr(&sp.tile_bits[ft], 0x80000000u)
-#endif
 
 // Diagnostic build (make STAMPS=1): s_memtime stamps at the phase boundaries of a wave
 // iteration, summed per wave and written to sp.stamps.  Never in the shipped kernel.
@@ -64,16 +59,12 @@ __global__ void __launch_bounds__(256, 2)
     k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
     constexpr bool STD = MODE != 0, S420 = MODE == 2;
     constexpr uint32_t kPasses = S420 ? 6u : 3u;
-#ifdef MI355_STD_CSC_VALU  // A/B builds: standard 4:4:4's colour conversion on the VALU as well
-    constexpr bool kCscMfma = false;
-#else
     // Standard 4:4:4 converts whole tiles on the matrix units (jpeg_screen_devfn.h: +4 %).  4:2:0 does not: the same
     // scheme for its chroma passes was built and measured at -1.5 % (profiles/r03_f_*) -- a matrix
     // instruction costs the issuing wave what 2.5 plain VALU instructions cost, the fixed-point form needs only four of
     // those per pixel, and the fragments' registers push the kernel to the limit beyond which the tail kernels stop
     // running beside it.
     constexpr bool kCscMfma = MODE == 1;
-#endif
     __shared__ uint32_t s_tbuf_all[kEncWaves][kRowWords];          // zig-zag rows, int16 [position][unit] (jpeg_screen_devfn.h)
     __shared__ alignas(16) uint32_t s_slot_all[kEncWaves][(kSlotRows + 1) * 64];  // AC strings [word][lane] + dump row
     __shared__ uint32_t s_mask_all[kEncWaves][2][64];              // non-zero masks (lo, hi)
@@ -299,11 +290,7 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
                 for (int i = 0; i < 12; ++i) cur[i] = raw[i];
                 if (j < 3) load_raw_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, raw);  // (two pairs in flight: -1 %)
-#ifdef MI355_DIAG_NOTIE  // timing experiment only (wrong in 1 luma sample of 1000): luma without the tie check
-                if (comp == 0) convert_rowpair<0, STD, true>(cur, false, pk);
-#else
                 if (comp == 0) convert_rowpair<0, STD>(cur, false, pk);
-#endif
                 else if (comp == 1) convert_rowpair<1, STD>(cur, avg, pk);
                 else convert_rowpair<2, STD>(cur, avg, pk);
             } else {
@@ -469,11 +456,7 @@ __global__ void __launch_bounds__(256, 2)
             // MI355_E_CAPACITY (strings beyond 9/4 of the output capacity: the output could not hold them either)
             if (lane == 0) atomicOr(sp.status, 2u), POISON_TILE();
         } else {
-#ifdef MI355_DIAG_NOARENA  // timing experiment only (wrong output): no AC strings written
-            const uint32_t ncopy = 0u;
-#else
             const uint32_t ncopy = oversize ? 0u : nw;
-#endif
 #pragma unroll
             for (uint32_t w = 0; w < 8; ++w)
                 if (w < ncopy) sp.arena[off + w] = s_slot[w * 64 + lane];

@@ -158,19 +158,6 @@ struct mi355_jpeg_ctx {
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
     uint8_t* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // scratch of the stage-by-stage entry points
     size_t stage_cap[4] = {0, 0, 0, 0};
-    // single-launch pipeline (jpeg_tile_kernels.hip)
-    int pipeline = 0;               // 0 (default; MI355_JPEG_PIPELINE=launches, and always for 4:2:0): block-encode kernel + three tail kernels;
-                                    // 1 (MI355_JPEG_PIPELINE=tile): the single-launch kernel k_encode_tile (strict and standard 4:4:4) -- 1.05 x
-                                    // the algorithmic HBM bytes and no workspace, but 10 % slower on batches
-    unsigned long long* d_rec = nullptr;
-    size_t rec_cap = 0;             // granules
-    uint32_t* d_ticket = nullptr;   // [frames] per-frame ticket counters
-    size_t ticket_cap = 0;
-    uint32_t* d_ovf = nullptr;
-    size_t ovf_cap = 0;             // words
-    uint32_t epoch = 0;
-    uint32_t tile_wgs = 256;        // workgroups of k_encode_tile / k_screen_encode_wide (one per CU)
-    int encode_shape = 0;           // block-encode kernel of the four-launch pipeline: 0 k_screen_encode (2 x 4 waves per CU), 1 k_screen_encode_wide (11 waves per CU)
     uint2* d_meta = nullptr;
     size_t meta_cap = 0;
     uint32_t* d_arena = nullptr;
@@ -427,10 +414,9 @@ struct ArenaPlan {
     uint32_t grid, region_words;
     size_t total_words;
 };
-bool wide_shape(const mi355_jpeg_ctx* c, const Geom& g) { return c->encode_shape == 1 && !is420(g); }
 ArenaPlan plan_arena(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, size_t need_words) {
     ArenaPlan p;
-    p.grid = wide_shape(c, g) ? wide_grid_waves(g, n_frames, c->tile_wgs) : screen_grid(g, n_frames, c->screen_waves);
+    p.grid = screen_grid(g, n_frames, c->screen_waves);
     p.region_words = (uint32_t)((need_words + p.grid - 1) / p.grid);
     p.total_words = (size_t)p.grid * p.region_words + need_words + (size_t)p.grid * 1024 + 64;
     return p;
@@ -648,10 +634,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         part.counter = i % kCounters;
         const ScreenParams sp = part_params(c, g, part, set_meta, set_arena);
         if (i >= nsets) HIP_TRY(hipStreamWaitEvent(s, c->ev_set[part.set], 0));  // the tails of part i - nsets are done with this set
-        if (wide_shape(c, g))
-            HIP_TRY(launch_screen_encode_wide(g, part.nf, d_rgb + (size_t)part.f0 * g.frame_stride, sp, part.plan.grid, s));
-        else
-            HIP_TRY(launch_screen_encode(g, part.nf, d_rgb + (size_t)part.f0 * g.frame_stride, sp, false, c->screen_waves, s));
+        HIP_TRY(launch_screen_encode(g, part.nf, d_rgb + (size_t)part.f0 * g.frame_stride, sp, false, c->screen_waves, s));
         if (i + 1 == nparts) {  // the last part's tails stay on the caller's stream
             record(c, 1, s);
             if ((e = launch_tails(c, g, part, sp, d_out, out_stride, d_bits, s, nparts == 1, n_frames))) return e;
@@ -669,52 +652,6 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         record(c, 3, s);
         record(c, 4, s);
     }
-    return MI355_OK;
-}
-
-// Single-launch pipeline: k_encode_tile (jpeg_tile_kernels.hip).  Event slots: [0,1] the kernel; the other slots
-// coincide with 1.  Device memory besides the caller's buffers: 64 bytes of hand-off granules per tile, one ticket
-// counter per frame, 13.5 KiB of string overflow area per resident wave -- nothing that scales with the output capacity.
-int run_tile(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint8_t* d_rgb, uint8_t* d_out, size_t out_stride,
-             uint64_t* d_bits, hipStream_t s) {
-    const uint32_t wgs = tile_grid(g, n_frames, c->tile_wgs);
-    TileParams tp;
-    memset(&tp, 0, sizeof tp);
-    ArenaPlan none{1, 0, 0};
-    tp.sp = screen_params(c, g, n_frames, none, nullptr);
-    tp.sp.prio_from_wg = 0xFFFFFFFFu;
-    int e;
-    const size_t granules = tile_rec_granules(g, n_frames);
-    const size_t tickets = ((size_t)n_frames + 3) & ~(size_t)3;
-    const bool fresh = granules > c->rec_cap || !c->d_rec;
-    if ((e = ensure(c->d_rec, c->rec_cap, granules, true)) || (e = ensure(c->d_ovf, c->ovf_cap, tile_ovf_words(wgs))) ||
-        (e = ensure(c->d_tile_off, c->tile_off_cap, tile_off_entries(g, n_frames))) ||
-        (e = ensure(c->d_ticket, c->ticket_cap, tickets)))
-        return e;
-    // the per-frame ticket counters start from zero in every launch (a memset node in stream order; a multiple of 16 bytes)
-    HIP_TRY(hipMemsetAsync(c->d_ticket, 0, tickets * sizeof(uint32_t), s));
-    // every launch tags its granules with a new epoch; records of earlier launches never match.  A fresh
-    // (zeroed) record array can start over; at the wrap the array is cleared in stream order.
-    if (fresh) c->epoch = 0;
-    if (++c->epoch > 0xFFFFu) {
-        HIP_TRY(hipMemsetAsync(c->d_rec, 0, c->rec_cap * sizeof(unsigned long long), s));
-        c->epoch = 1;
-    }
-    tp.rec = c->d_rec;
-    tp.ticket = c->d_ticket;
-    tp.epoch = c->epoch;
-    tp.ovf = c->d_ovf;
-    tp.out = d_out;
-    tp.out_stride = out_stride;
-    tp.frame_bits = d_bits;
-    tp.tile_off = c->d_tile_off;
-    record(c, 0, s);
-    c->last_launches = 1;
-    HIP_TRY(launch_encode_tile(g, n_frames, d_rgb, tp, wgs, s));
-    record(c, 1, s);
-    record(c, 2, s);
-    record(c, 3, s);
-    record(c, 4, s);
     return MI355_OK;
 }
 
@@ -746,8 +683,6 @@ struct Knobs {
     double tau_scale = 1.0;
     uint32_t batch_parts = 0xFFFFu;
     uint32_t max_sets = 0;
-    int encode_shape = 0;
-    int pipeline = 0;
     uint32_t screen_waves = 0;  // 0: the device's default
     uint32_t stagger = 0;
 };
@@ -779,16 +714,6 @@ bool read_knobs(Knobs* k) {
     }
     if (knob_uint("MI355_JPEG_BATCH_PARTS", 1, 8, &kv)) k->batch_parts = (uint32_t)kv;
     if (knob_uint("MI355_JPEG_MAX_SETS", 2, 64, &kv)) k->max_sets = (uint32_t)kv;
-    if (const char* pl = getenv("MI355_JPEG_PIPELINE")) {
-        if (!strcmp(pl, "tile")) k->pipeline = 1;
-        else if (!strcmp(pl, "launches")) k->pipeline = 0;
-        else bad = true;
-    }
-    if (const char* es = getenv("MI355_JPEG_ENCODE_SHAPE")) {
-        if (!strcmp(es, "wide")) k->encode_shape = 1;
-        else if (!strcmp(es, "classic")) k->encode_shape = 0;
-        else bad = true;
-    }
     if (knob_uint("MI355_JPEG_SCREEN_WAVES", 32, 8192, &kv)) {
         if (kv & 31) bad = true;
         else k->screen_waves = (uint32_t)kv;
@@ -856,9 +781,6 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     c->batch_parts = kn.batch_parts;
     c->max_sets = kn.max_sets;
     c->stagger = kn.stagger;
-    c->encode_shape = kn.encode_shape;
-    c->pipeline = kn.pipeline;
-    if (c->n_cus > 0) c->tile_wgs = (uint32_t)c->n_cus;
     if (kn.screen_waves) (void)mi355_jpeg_set_encode_waves(c, kn.screen_waves);  // one place derives every grid from it
     int e = MI355_OK;
     if (hipMalloc((void**)&c->d_q, 128 * sizeof(double)) != hipSuccess ||
@@ -898,7 +820,7 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     void* ptrs[] = {c->d_q,        c->d_lut,      c->d_status, c->d_coefs,  c->d_unit_off, c->d_tile_bits,
                     c->d_tile_off, c->d_in,       c->d_out,    c->d_bits,   c->d_afrag,    c->d_qconst,
                     c->d_counters, c->d_meta,     c->d_arena,  c->d_lut2,     c->d_qconst_f,
-                    c->d_stuff_counts, c->d_stuff_offs, c->d_qzz, c->d_stats, c->d_rec, c->d_ticket, c->d_ovf};
+                    c->d_stuff_counts, c->d_stuff_offs, c->d_qzz, c->d_stats};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (void* p : c->d_stage)
@@ -954,7 +876,6 @@ int mi355_jpeg_set_huffman(mi355_jpeg_ctx* c, int table, const mi355_huff_table*
 int mi355_jpeg_set_encode_waves(mi355_jpeg_ctx* c, uint32_t waves) {
     if (!c || (waves != 0 && (waves < 32 || waves > 8192 || (waves & 31)))) return MI355_E_ARG;
     c->screen_waves = waves ? waves : (c->n_cus > 0 ? 8u * (uint32_t)c->n_cus : 2048u);
-    c->tile_wgs = c->screen_waves / 8u ? c->screen_waves / 8u : 1u;  // the same share of the device: one workgroup per CU
     return MI355_OK;
 }
 
@@ -1008,8 +929,6 @@ int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t
     if ((flags & MI355_F_STANDARD) && c->transform_mode != 2) return MI355_E_ARG;  // the exact pipeline is strict only
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
-    if (c->transform_mode == 2 && c->pipeline == 1 && !is420(g))
-        return run_tile(c, g, n_frames, (const uint8_t*)d_rgb, (uint8_t*)d_out, out_stride, d_bits, s);
     if (c->transform_mode == 2) {
         // only unit_off / tile arrays of the classic workspace are needed
         if ((e = ensure(c->d_unit_off, c->unit_off_cap, unit_off_words(g) * n_frames))) return e;
@@ -1030,29 +949,7 @@ int mi355_jpeg_sync(mi355_jpeg_ctx* c, void* stream) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
 #ifdef MI355_STAMPS
-    if (c->d_stamps && getenv("MI355_JPEG_DUMP_STAMPS") && c->pipeline == 1) {
-        // k_encode_tile: [wave][16], wave = 3 * team + channel
-        const size_t waves = (size_t)c->tile_wgs * 12;
-        std::vector<unsigned long long> h(waves * 16);
-        (void)hipMemcpy(h.data(), c->d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
-        static const char* names[11] = {"head", "samples", "quantise", "walk", "dc+totals", "meet1", "scan+append", "lookback", "meet2", "writeout", "word0"};
-        for (int ch = 0; ch < 3; ++ch) {
-            double sum[11] = {0}, tiles = 0, wall = 0;
-            size_t nw = 0;
-            for (size_t w = ch; w < waves; w += 3) {
-                if (!h[w * 16 + 14]) continue;
-                for (int i = 0; i < 11; ++i) sum[i] += (double)h[w * 16 + i];
-                tiles += (double)h[w * 16 + 14];
-                wall += (double)(h[w * 16 + 15] - h[w * 16 + 13]) * 0.01;
-                ++nw;
-            }
-            fprintf(stderr, "[tstamps] chan %d: %zu waves, %.1f tiles/wave, wall %.1f us/wave | cycles per tile:", ch, nw, tiles / (nw ? nw : 1), wall / (nw ? nw : 1));
-            double tot = 0;
-            for (int i = 0; i < 11; ++i) fprintf(stderr, " %s %.0f", names[i], sum[i] / (tiles ? tiles : 1)), tot += sum[i];
-            fprintf(stderr, " | total %.0f\n", tot / (tiles ? tiles : 1));
-        }
-    }
-    if (c->d_stamps && getenv("MI355_JPEG_DUMP_STAMPS") && c->pipeline == 0) {
+    if (c->d_stamps && getenv("MI355_JPEG_DUMP_STAMPS")) {
         std::vector<unsigned long long> h(4096 * 8);
         (void)hipMemcpy(h.data(), c->d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
         double sum[8] = {0};

@@ -146,7 +146,6 @@ def test_category_error_matches_oracle(jpeg, enc):
 def test_emit_direct_path_equals_lds_path(jpeg, monkeypatch):
     """Four-launch pipeline, k_merge: tiles whose bits exceed the LDS window take the direct-to-global path:
     force it for every tile and compare."""
-    monkeypatch.setenv("MI355_JPEG_PIPELINE", "launches")
     rgb = ol.lcg_frame(640, 360, 3)
     ql, qc = ol.quant_tables(90)
     o = ol.oracle_encode(rgb, ql, qc, False)
@@ -746,17 +745,12 @@ def test_screen_counters_are_exposed(jpeg):
     e2.close()
 
 
-@pytest.mark.parametrize("pipeline", ["tile", "launches", "launches-wide"])
-def test_both_pipelines_are_bit_identical(jpeg, monkeypatch, pipeline):
-    """MI355_JPEG_PIPELINE=tile (the single-launch kernel of jpeg_tile_kernels.hip -- three waves per tile, in-kernel
-    look-back scan + merge) and =launches (the default: block-encode kernel + three tail kernels) against the
-    oracle: ragged sizes, one-tile and many-tile frames, batches (several frames per look-back group and several
-    groups), high quality (strings longer than their LDS slot, tiles larger than the bit window), the capacity
-    error, and the stage probes."""
-    if pipeline == "launches-wide":  # the four-launch pipeline with the 11-waves-per-CU block-encode kernel (jpeg_wide_kernels.hip)
-        monkeypatch.setenv("MI355_JPEG_ENCODE_SHAPE", "wide")
-        pipeline = "launches"
-    monkeypatch.setenv("MI355_JPEG_PIPELINE", pipeline)
+def test_pipeline_sweep_against_the_oracle(jpeg):
+    """The pipeline (block-encode kernel + three tail kernels) against the oracle in one sweep: ragged sizes,
+    one-tile and many-tile frames, batches, high quality (strings longer than their LDS slot, tiles larger than
+    the bit window), the capacity error, the stage probes, and standard 4:4:4 with restart intervals.  (Round 3
+    ran this over three kernel shapes; the two that lost their A/B -- k_encode_tile, k_screen_encode_wide -- were
+    removed in round 4, git tag r03-all-shapes keeps them.)"""
     e2 = jpeg.Encoder(0)
     rng = np.random.default_rng(7)
     for (W, H, q, cds) in [(8, 8, 50, True), (253, 254, 50, True), (640, 360, 50, True), (1000, 37, 90, False),
@@ -893,14 +887,12 @@ def test_config4_per_gpu_share_1024_4k_frames_through_the_pool(jpeg):
     e2.close()
 
 
-@pytest.mark.parametrize("pipeline", ["launches", "tile"])
-def test_per_frame_error_reporting(jpeg, monkeypatch, pipeline):
+def test_per_frame_error_reporting(jpeg):
     """one frame of a batch does not fit its output slot.  mi355_jpeg_sync reports
     MI355_E_CAPACITY, that frame's bit count is UINT64_MAX, and the other seven frames are complete and equal
     to the oracle (before: everything issued since the last sync was undefined).  Then a coefficient without a
     code in one frame (MI355_E_CATEGORY): same contract."""
     import torch
-    monkeypatch.setenv("MI355_JPEG_PIPELINE", pipeline)
     e2 = jpeg.Encoder(0)
     ql, qc = set_quality(e2, 50)
     W, H, n = 320, 200, 8
@@ -968,7 +960,6 @@ def test_parts_that_share_workspace_sets(jpeg, monkeypatch):
     """A batch whose parts do not all get a workspace set of their own (MI355_JPEG_MAX_SETS=2 forces what a nearly
     full device does by itself): part i reuses the set of part i - 2 after that part's tail kernels; same bits."""
     monkeypatch.setenv("MI355_JPEG_MAX_SETS", "2")
-    monkeypatch.setenv("MI355_JPEG_PIPELINE", "launches")
     e2 = jpeg.Encoder(0)
     ql, qc = set_quality(e2, 50)
     W, H, n = 1920, 1080, 256
@@ -1020,8 +1011,7 @@ def test_batch_at_worst_case_capacity_is_accepted(jpeg, enc):
             assert ascii_sha(d_out[f, :(g[0] + 7) // 8].cpu().numpy(), g[0]) == g[1], (n, f)
             checked += 1
         assert checked >= 4
-        if os.environ.get("MI355_JPEG_PIPELINE") != "tile":  # (the single-launch pipeline has no parts)
-            assert enc.last_call_parts() >= n // 20
+        assert enc.last_call_parts() >= n // 20
         del d_rgb, d_out, d_bits
         torch.cuda.empty_cache()
 

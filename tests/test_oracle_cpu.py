@@ -269,19 +269,16 @@ def test_exactness_knobs_are_refused_before_any_device_is_touched(monkeypatch):
     bad = [("MI355_JPEG_SCREEN_TAU_SCALE", v) for v in ("0.5", "0", "nan", "inf", "-1", "1e", "", "0.999999")] + \
           [("MI355_JPEG_TRANSFORM_MODE", v) for v in ("3", "-1", "x", "2x", "")] + \
           [("MI355_JPEG_EMIT_LDS_WORDS", v) for v in ("-1", "5000", "abc")] + \
-          [("MI355_JPEG_PIPELINE", v) for v in ("fused", "", "Tile")] + \
           [("MI355_JPEG_SCREEN_WAVES", v) for v in ("33", "0", "100000")] + \
           [("MI355_JPEG_BATCH_PARTS", v) for v in ("0", "9")] + \
           [("MI355_JPEG_STAGGER", v) for v in ("65", "-1", "2x")] + \
-          [("MI355_JPEG_ENCODE_SHAPE", v) for v in ("Wide", "")] + \
           [("MI355_JPEG_MAX_SETS", v) for v in ("1", "65")]
     for name, v in bad:
         monkeypatch.setenv(name, v)
         assert create() == jpeg.E_ARG, (name, v)
         monkeypatch.delenv(name)
     good = [("MI355_JPEG_SCREEN_TAU_SCALE", "1"), ("MI355_JPEG_SCREEN_TAU_SCALE", "1e6"), ("MI355_JPEG_TRANSFORM_MODE", "0"),
-            ("MI355_JPEG_PIPELINE", "launches"), ("MI355_JPEG_PIPELINE", "tile"), ("MI355_JPEG_SCREEN_WAVES", "1024"),
-            ("MI355_JPEG_STAGGER", "0"), ("MI355_JPEG_STAGGER", "64"), ("MI355_JPEG_ENCODE_SHAPE", "wide")]
+            ("MI355_JPEG_SCREEN_WAVES", "1024"), ("MI355_JPEG_STAGGER", "0"), ("MI355_JPEG_STAGGER", "64")]
     for name, v in good:
         monkeypatch.setenv(name, v)
         assert create() == base, (name, v)
