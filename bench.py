@@ -29,6 +29,11 @@ Prints ONE JSON line on rank 0:
                 ALL the run's GPUs (PCIe both ways; Gpixel/s and H2D GB/s per GPU) -- never `value`;
   standard_mode secondary: the decodable 4:2:0 baseline mode (not a behaviour of the reference);
   single_call_latency_ms   one 4K frame per call, one call at a time.
+  other_configs the other BASELINE configurations and SURVEY §8(d)'s natural-statistics input, each gated on a golden
+                of the reference build first (tests/golden/cases.json; 16384^2: SURVEY Appendix B), each with Mpixel/s,
+                algorithmic GB/s and fraction of the HBM roof by §8(d)'s formula: configs[2] (256 x 1080p q75 per call),
+                configs[4] (one 16384x16384 q90 frame without chroma averaging), fruit.ppm tiled to 3840x2160 in strict
+                mode and in standard 4:2:0 -- secondary, never `value`.
 All outputs written in the timed region are re-verified after it (see verify_outputs).
 """
 import argparse
@@ -52,7 +57,8 @@ GOLDEN_SEED1_BITS = 38227880
 GOLDEN_SEED1_SHA = "6a4a20a6412d6e3bfd878e09875156170ff80a74d7c10c04b52a425e7dbcf009"
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_FP64_OPS_PER_UNIT = 12416   # 64*64*3 + 64 + 64 per (block, channel)
-DTYPE = "i8-mfma + fp32 screen, f64 arbiter (results bit-identical to the reference's f64 path)"
+DTYPE = "f16/i8-mfma + fp32 screen, f64 arbiter (results bit-identical to the reference's f64 path)"
+GOLDEN_16K = (3938207090, "22a3a76e3a7ceb82d483d31262f3b67bce5668bed019bcca7f457094bb64fe54")  # 16384^2 LCG seed 1, q90, no averaging
 
 
 def golden_4k():
@@ -102,6 +108,118 @@ def gate_other_quality(enc, torch, dev):
     assert nb == c["n_bits"], "q90 gate: %d bits, reference %d" % (nb, c["n_bits"])
     assert ascii_sha(o[0, :(nb + 7) // 8].cpu().numpy(), nb) == c["sha256_ascii_bits"], "q90 gate: scan bits differ from the reference"
     return c["name"]
+
+
+def ascii_sha_chunked(packed_torch_u8, nb, chunk=16 << 20):
+    """ascii_sha of a long scan without holding its 8-fold expansion: the packed bytes come from the device in pieces."""
+    h = hashlib.sha256()
+    nbytes = (nb + 7) // 8
+    for lo in range(0, nbytes, chunk):
+        hi = min(lo + chunk, nbytes)
+        bits = np.unpackbits(packed_torch_u8[lo:hi].cpu().numpy())
+        if hi == nbytes:
+            bits = bits[:nb - lo * 8]
+        h.update((bits + ord("0")).astype(np.uint8).tobytes())
+    return h.hexdigest()
+
+
+def tiled_fruit(w, h):
+    """SURVEY §8(d)'s natural-statistics input: src[(y mod 254) * 253 + (x mod 253)] of the reference's data/fruit.ppm
+    (tests/golden/fruit.ppm is that file)."""
+    with open(os.path.join(ROOT, "tests", "golden", "fruit.ppm"), "rb") as f:
+        assert f.readline().strip() == b"P6"
+        fw, fh = (int(v) for v in f.readline().split())
+        assert int(f.readline()) == 255
+        fruit = np.frombuffer(f.read(fw * fh * 3), np.uint8).reshape(fh, fw, 3)
+    return np.ascontiguousarray(fruit[np.arange(h) % fh][:, np.arange(w) % fw])
+
+
+def other_configs_leg(jpeg, enc, torch, dev, stream):
+    """The BASELINE configurations besides the headline one and SURVEY §8(d)'s natural input, device-resident, one call
+    shape each, gated on a golden before it is timed.  Algorithmic bytes per frame = 3 W H + ceil(bits / 8)."""
+    out = []
+
+    def run(name, w, h, n, quality, flags, fill, gate, reps, note):
+        enc.set_quality(quality)
+        d = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+        fill(d)
+        enc.sync()
+        cap = gate["cap"]
+        o = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
+        b = torch.zeros(n, dtype=torch.int64, device=dev)
+
+        def go():
+            enc.encode_scan_device(d.data_ptr(), w, h, n, o.data_ptr(), cap, b.data_ptr(), flags=flags, stream=stream)
+
+        go()
+        enc.sync(stream)
+        nb0 = int(b[0])
+        assert nb0 == gate["n_bits"], "%s: frame 0 has %d bits, golden %d" % (name, nb0, gate["n_bits"])
+        if "sha_ascii" in gate:
+            assert ascii_sha_chunked(o[0], nb0) == gate["sha_ascii"], "%s: scan bits differ from the reference" % name
+        else:
+            assert hashlib.sha256(o[0, :(nb0 + 7) // 8].cpu().numpy().tobytes()).hexdigest() == gate["sha_packed"], \
+                "%s: scan bytes differ from the checker's fixture" % name
+        enc.walk_stats(reset=True)
+        enc.set_profiling(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            go()
+        enc.sync(stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        prof, calls = enc.profile_summary()
+        enc.set_profiling(0)
+        rewalked, general = enc.walk_stats(reset=True)
+        bits = b.cpu().numpy().astype(np.int64)
+        assert (bits > 0).all() and (bits <= 8 * cap).all(), name
+        alg = 3.0 * w * h + float(np.mean((bits + 7) // 8))
+        gbps = alg * n / dt / 1e9
+        t_k = prof["transform_ms"] / max(calls, 1) * 1e-3
+        units = n * (-(-w // 8)) * (-(-h // 8)) * 3
+        rec = {"case": name, "value": round(n * w * h / dt / 1e6, 1), "unit": "Mpixel/s", "frames_per_call": n, "ms_per_call": round(dt * 1e3, 4),
+               "bits_per_pixel": round(float(bits.mean()) / (w * h), 4), "algorithmic_bytes_per_frame": int(alg),
+               "achieved_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 5),
+               "block_encode_kernel_ms_per_call": round(t_k * 1e3, 4), "block_encode_kernel_GBps": round(alg * n / t_k / 1e9, 1),
+               "gated_on": gate["what"], "note": note}
+        if not (flags & jpeg.F_STANDARD):
+            rec["strings_walked_twice_per_unit"] = round(rewalked / float(reps * units), 4)
+            rec["passes_in_general_walk_loop"] = round(general / float(reps * units / 64.0), 4)
+        out.append(rec)
+        del d, o, b
+        torch.cuda.empty_cache()
+
+    def lcg(seed0):
+        return lambda d: enc.synth_lcg_device(d.data_ptr(), d.shape[1] * d.shape[2] * 3, d.shape[0], seed0)
+
+    def fruit(d):
+        f = torch.from_numpy(tiled_fruit(d.shape[2], d.shape[1])).to(d.device)
+        d[:] = f
+
+    try:
+        c = golden_case("lcg_1920x1080_s1_q75_cds")
+        run("configs[2]: 256 x 1920x1080 LCG frames per call (of the 1024), q75, chroma averaging on, strict", 1920, 1080, 256, 75,
+            jpeg.F_DEFAULT, lcg(1), {"n_bits": c["n_bits"], "sha_ascii": c["sha256_ascii_bits"], "cap": 3 << 20,
+                                     "what": "tests/golden/cases.json lcg_1920x1080_s1_q75_cds (reference build)"}, 4,
+            "Huffman prefix-scan throughput (BASELINE)")
+        run("configs[4]: one 16384x16384 LCG frame, q90, no chroma averaging, strict", 16384, 16384, 1, 90, 0, lcg(1),
+            {"n_bits": GOLDEN_16K[0], "sha_ascii": GOLDEN_16K[1], "cap": 520 << 20, "what": "SURVEY Appendix B (reference build): 3 938 207 090 bits, 22a3a76e..."},
+            4, "DCT/quant HBM-roofline stress (BASELINE): 14.7 bit/px, most luma strings exceed their 24-word slot in LDS and are "
+               "coded a second time straight into device memory (strings_walked_twice_per_unit)")
+        c = golden_case("fruit_tiled_3840x2160_q50_cds")
+        run("natural statistics, strict: fruit.ppm tiled to 3840x2160, 128 frames per call, q50, chroma averaging on", W, H, 128, 50,
+            jpeg.F_DEFAULT, fruit, {"n_bits": c["n_bits"], "sha_ascii": c["sha256_ascii_bits"], "cap": 8 << 20,
+                                    "what": "tests/golden/cases.json fruit_tiled_3840x2160_q50_cds (reference build; SURVEY Appendix B a23fc925...)"}, 4,
+            "SURVEY §8(d)'s secondary input; the reference's in-place chain is not a DCT, so even a photograph keeps 4.7 bit/px here")
+        c = golden_case("std420_fruit_tiled_3840x2160_q50")
+        run("natural statistics, standard 4:2:0: fruit.ppm tiled to 3840x2160, 128 frames per call, q50", W, H, 128, 50,
+            jpeg.F_STANDARD | jpeg.F_420, fruit, {"n_bits": c["n_bits"], "sha_packed": c["sha256_packed_bits"], "cap": 4 << 20,
+                                                 "what": "tests/golden/cases.json std420_fruit_tiled_3840x2160_q50 (the checker's fixture: this mode is not a behaviour of the reference)"},
+            6, "the decodable mode on a photograph: 1.6 bit/px, a third of the symbols of noise")
+    finally:
+        enc.set_quality(QUALITY)
+    return out
 
 
 def kernel_sources_sha():
@@ -468,10 +586,12 @@ def worker(args):
             "verified": {"frames_vs_reference_sha_before": n_gold, "frames_vs_reference_sha_after": n_gold_after,
                          "all_frames_bytes_equal_isolated_call_after_region": True,
                          "second_operating_point_before": other_gate},
-            "roofline": {"bound": "hbm", "limited_by": "VALU instruction issue (see `binding` and `valu_issue`): the HBM roof is what "
-                                                       "the metric is priced against, not what binds the kernel",
+            "roofline": {"bound": "valu_issue",
+                         "limited_by": "instruction issue of the two resident waves per SIMD (see `binding` and `valu_issue`); achieved / peak / frac "
+                                       "below are SURVEY §8(d)'s algorithmic bytes against the HBM roof -- what the metric is priced "
+                                       "against, not what binds the kernel",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "hbm_frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": None if traffic is None else int(traffic * frames_per_launch),
                          "traffic_source": traffic_src,
                          "kernel": "k_screen_encode", "kernel_ms": round(t_launch * 1e3, 5),
@@ -521,6 +641,10 @@ def worker(args):
                 line["standard_mode"] = standard_mode_leg(jpeg, enc, d_rgb, d_out, d_bits, cap, stream, F, torch, args)
             except Exception as exc:  # pragma: no cover
                 line["standard_mode"] = {"error": str(exc)}
+        try:
+            line["other_configs"] = other_configs_leg(jpeg, enc, torch, dev, stream)
+        except Exception as exc:  # pragma: no cover
+            line["other_configs"] = {"error": repr(exc)}
         try:  # all the run's GPUs through the pool (the other ranks are idle on the CPU by now)
             devs = [r if not args.share_device else r % max(ndev, 1) for r in range(args.gpus)]
             line["end_to_end"] = end_to_end_leg(jpeg, d_rgb, devs, torch, golden, seed0)

@@ -31,9 +31,13 @@
 extern "C" {
 #endif
 
-#define MI355_JPEG_ABI_VERSION 3
+#define MI355_JPEG_ABI_VERSION 4
 
 typedef struct mi355_jpeg_ctx mi355_jpeg_ctx;
+
+/* No C++ exception crosses this boundary: every entry point catches what the host side may throw (std::bad_alloc and
+ * a std::thread that cannot start -> MI355_E_ALLOC, anything else -> MI355_E_INTERNAL).  The reference's counterpart
+ * is -1 plus a message on stdout (utils.cpp:17-63). */
 
 enum mi355_jpeg_status {
     MI355_OK = 0,
@@ -45,7 +49,10 @@ enum mi355_jpeg_status {
     MI355_E_ALLOC = -5,      /* device or host allocation failed */
     MI355_E_TABLE = -6,      /* malformed quantisation / Huffman table; a container asked for with quantiser
                                 entries > 255 (an 8-bit DQT cannot hold them) */
-    MI355_E_INTERNAL = -7,   /* a device-side wait gave up (should never happen; results of the call are invalid) */
+    MI355_E_INTERNAL = -7,   /* an internal invariant failed, or an exception other than an allocation failure was stopped at
+                                this boundary (should never happen; results of the call are invalid) */
+    MI355_E_NOT_ENCODED = -8, /* per-frame status only (mi355_jpeg_pool_encode_ex): the call ended -- with the error it
+                                returns -- before this frame was delivered */
     MI355_E_HIP = -100       /* MI355_E_HIP - hipError_t */
 };
 
@@ -162,9 +169,10 @@ int mi355_jpeg_encode_scan(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, 
 /* Device buffers in, device buffers out, asynchronous on `stream` (a
  * hipStream_t, NULL = default stream).  d_bits: device array of n_frames
  * uint64.  Errors detected on the device (capacity, category) are reported by
- * the next mi355_jpeg_sync(), and PER FRAME in d_bits: a frame whose scan does not fit
- * out_stride, or that holds a coefficient without a code, gets d_bits[f] = UINT64_MAX
- * (its output bytes are undefined); every other frame of the call is complete and valid.
+ * the next mi355_jpeg_sync(), and PER FRAME in d_bits, with the cause: a frame that holds a coefficient without a
+ * code gets d_bits[f] = MI355_BITS_CATEGORY, one whose scan does not fit out_stride MI355_BITS_CAPACITY (its output
+ * bytes are undefined; d_bits[f] >= MI355_BITS_FLAGGED tests for either); every other frame of the call is complete
+ * and valid, whatever its neighbours hold -- the device workspace of a frame cannot be used up by another one.
  *
  * n_frames: 1 .. 65535, any out_stride >= 8 (a multiple of 4); a batch is never refused for its
  * size: it is cut into parts of ~16 4K frames' worth of pixels, each with 32-bit offsets of its own.
@@ -175,12 +183,15 @@ int mi355_jpeg_encode_scan(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, 
  * a part then waits for the tail kernels of the part whose set it reuses); plus 12 bytes per tile (64
  * blocks) for every frame.  E.g. 128 4K frames at out_stride = 8 MiB: 8 parts, 5.7 GB; at out_stride =
  * mi355_jpeg_scan_bound (84 MB): 22 GB. */
+#define MI355_BITS_CAPACITY UINT64_MAX        /* = MI355_E_CAPACITY for this frame */
+#define MI355_BITS_CATEGORY (UINT64_MAX - 1)  /* = MI355_E_CATEGORY for this frame (ABI 4; ABI 3 wrote UINT64_MAX for both) */
+#define MI355_BITS_FLAGGED (UINT64_MAX - 1)
 int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx *ctx, const void *d_rgb, uint32_t W, uint32_t H,
                                   uint32_t n_frames, uint32_t flags, void *d_out,
                                   size_t out_stride, uint64_t *d_bits, void *stream);
 /* Waits for `stream`, then returns the first device-side error of the calls
  * issued since the previous sync (MI355_OK if none).  After MI355_E_CAPACITY / MI355_E_CATEGORY the
- * frames at fault are the ones whose d_bits entry is UINT64_MAX; all other frames of those calls are
+ * frames at fault are the ones whose d_bits entry is >= MI355_BITS_FLAGGED; all other frames of those calls are
  * good.  After MI355_E_INTERNAL everything issued since the previous sync must be discarded. */
 int mi355_jpeg_sync(mi355_jpeg_ctx *ctx, void *stream);
 
@@ -273,8 +284,8 @@ int mi355_jpeg_stuff_device(mi355_jpeg_ctx *ctx, const void *d_scan, const uint6
 /* ---- multi-GPU batch driver (host frames in, host scans out) -------------
  * The production shape of BASELINE configs[3]: a batch of independent frames sharded
  * across the GPUs of one node, no collective.  One worker thread + one context per
- * entry of device_ids (an id may repeat: several workers on one GPU); each worker takes
- * a contiguous slab of frames and streams it through the device in chunks with
+ * entry of device_ids (an id may repeat: several workers on one GPU); each worker pulls
+ * chunks of frames from the call's shared cursor and streams them through its device with
  * H2D(k+1) || encode(k) || D2H(k-1) on separate HIP streams.  Same results as
  * mi355_jpeg_encode_scan frame by frame.
  *
@@ -289,6 +300,8 @@ void mi355_jpeg_pool_destroy(mi355_jpeg_pool *pool);
 int mi355_jpeg_pool_workers(mi355_jpeg_pool *pool);
 int mi355_jpeg_pool_set_quant(mi355_jpeg_pool *pool, const uint32_t qlum[64], const uint32_t qchrom[64]);
 int mi355_jpeg_pool_set_quality(mi355_jpeg_pool *pool, int quality);
+/* mi355_jpeg_set_huffman on every context of the pool (ABI 4). */
+int mi355_jpeg_pool_set_huffman(mi355_jpeg_pool *pool, int table, const mi355_huff_table *t);
 /* Streaming callers: register the host buffers they reuse (frame rings, output slabs) once; encode calls whose
  * rgb / out lie inside a registered range do no registration work of their own.  Memory that is not registered
  * this way is registered for the duration of each call (each buffer as one range, on the calling thread).  The
@@ -301,9 +314,14 @@ int mi355_jpeg_pool_encode(mi355_jpeg_pool *pool, const uint8_t *rgb, uint32_t W
                            uint32_t n_frames, uint32_t flags, uint8_t *out, size_t out_stride,
                            uint64_t *bits, double *seconds);
 /* The same with a per-frame status array (may be NULL): frame_status[f] = MI355_OK, or MI355_E_CAPACITY /
- * MI355_E_CATEGORY for a frame that did not fit out_stride / holds a coefficient without a code (bits[f] =
- * UINT64_MAX, out bytes undefined).  Every other frame of the batch is returned in full, whatever shard it was
- * in; the call returns the first such error (MI355_OK if none). */
+ * MI355_E_CATEGORY -- each frame's OWN cause -- for a frame that did not fit out_stride / holds a coefficient without
+ * a code (bits[f] = MI355_BITS_CAPACITY / MI355_BITS_CATEGORY, out bytes undefined).  Every other frame of the batch
+ * is returned in full, whichever worker took it.  The call returns MI355_E_CATEGORY if any frame had that, else
+ * MI355_E_CAPACITY if any had that, else MI355_OK -- unless a worker ended on a hard error (HIP, allocation): then
+ * that error is returned and the frames it never delivered read MI355_E_NOT_ENCODED / MI355_BITS_CAPACITY (both arrays
+ * are initialised to that before the workers start).
+ * Frames are handed out to the workers in chunks from a shared cursor (about 256 MB of input, smaller for small
+ * batches): a slower GPU takes fewer chunks instead of setting the time of the call. */
 int mi355_jpeg_pool_encode_ex(mi355_jpeg_pool *pool, const uint8_t *rgb, uint32_t W, uint32_t H,
                               uint32_t n_frames, uint32_t flags, uint8_t *out, size_t out_stride,
                               uint64_t *bits, int *frame_status, double *seconds);
@@ -334,10 +352,16 @@ int mi355_jpeg_last_call_launches(mi355_jpeg_ctx *ctx, uint32_t *block_encode_la
  * all five digits were consulted; exact_units: units left undecided by both looks and recomputed with the
  * reference's ordered fp64 chain (the arbiter).  On noise exact_units / units is ~1e-7; a regression of
  * the accept thresholds to "accept everything" shows up as both counters stuck at zero on inputs built
- * to sit on rounding boundaries (tests/test_screen_pinning.py). */
+ * to sit on rounding boundaries (tests/test_screen_pinning.py).
+ * ABI 4 adds the two counters of the entropy walk (HuffmanEncoder, utils.cpp:656-698): rewalked_units: units whose AC
+ * string was longer than its 24-word slot in on-chip memory and was therefore coded a second time straight into device
+ * memory (noise at q >= 90: most luma units; q50: none); general_passes: (tile, channel) passes coded by the general
+ * walk loop (values beyond +-31 or a table with holes) instead of the branch-free one. */
 typedef struct mi355_jpeg_screen_counts {
     uint64_t second_looks;
     uint64_t exact_units;
+    uint64_t rewalked_units;
+    uint64_t general_passes;
 } mi355_jpeg_screen_counts;
 int mi355_jpeg_screen_stats(mi355_jpeg_ctx *ctx, void *stream, mi355_jpeg_screen_counts *out, int reset);
 

@@ -24,7 +24,9 @@ F_420 = 4       # with F_STANDARD: real 4:2:0 MCUs
 F_RESTART = 8   # with F_STANDARD: restart intervals of 64 MCUs (DRI/RSTm written by encode_jfif)
 F_DEFAULT = F_CDS
 
-OK, E_ARG, E_NO_DEVICE, E_CAPACITY, E_CATEGORY, E_ALLOC, E_TABLE, E_INTERNAL, E_HIP = 0, -1, -2, -3, -4, -5, -6, -7, -100
+OK, E_ARG, E_NO_DEVICE, E_CAPACITY, E_CATEGORY, E_ALLOC, E_TABLE, E_INTERNAL, E_NOT_ENCODED, E_HIP = 0, -1, -2, -3, -4, -5, -6, -7, -8, -100
+# per-frame verdicts in the bit-count array of a batched call (include/mi355_jpeg.h)
+BITS_CAPACITY, BITS_CATEGORY, BITS_FLAGGED = 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFE, 0xFFFFFFFFFFFFFFFE
 
 
 class HuffTable(C.Structure):
@@ -37,7 +39,8 @@ class Timings(C.Structure):
 
 
 class ScreenStats(C.Structure):
-    _fields_ = [("second_looks", C.c_uint64), ("exact_units", C.c_uint64)]
+    _fields_ = [("second_looks", C.c_uint64), ("exact_units", C.c_uint64), ("rewalked_units", C.c_uint64),
+                ("general_passes", C.c_uint64)]
 
 
 class JpegError(RuntimeError):
@@ -55,7 +58,7 @@ ABI_SYMBOLS = [
     "mi355_jpeg_probe_samples", "mi355_jpeg_probe_coefficients", "mi355_jpeg_probe_unit_bits",
     "mi355_jpeg_entropy_only", "mi355_jpeg_set_profiling", "mi355_jpeg_last_timings",
     "mi355_jpeg_profile_summary", "mi355_jpeg_synth_lcg_device", "mi355_jpeg_stuff_device", "mi355_jpeg_pool_create", "mi355_jpeg_pool_destroy", "mi355_jpeg_pool_workers",
-    "mi355_jpeg_pool_set_quant", "mi355_jpeg_pool_set_quality", "mi355_jpeg_pool_encode", "mi355_jpeg_pool_encode_ex",
+    "mi355_jpeg_pool_set_quant", "mi355_jpeg_pool_set_quality", "mi355_jpeg_pool_set_huffman", "mi355_jpeg_pool_encode", "mi355_jpeg_pool_encode_ex",
     "mi355_jpeg_pool_register", "mi355_jpeg_pool_unregister", "mi355_jpeg_pool_debug_counts",
     "mi355_jpeg_set_encode_waves", "mi355_jpeg_wrap_jfif", "mi355_jpeg_scan_bound_flags",
     "mi355_jpeg_last_call_launches", "mi355_jpeg_screen_stats",
@@ -131,6 +134,7 @@ def lib():
         L.mi355_jpeg_pool_workers.argtypes = [vp]
         L.mi355_jpeg_pool_set_quant.argtypes = [vp, vp, vp]
         L.mi355_jpeg_pool_set_quality.argtypes = [vp, C.c_int]
+        L.mi355_jpeg_pool_set_huffman.argtypes = [vp, C.c_int, C.POINTER(HuffTable)]
         L.mi355_jpeg_pool_encode.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, u64p, C.POINTER(C.c_double)]
         L.mi355_jpeg_pool_encode_ex.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, u64p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.mi355_jpeg_pool_register.argtypes = [vp, vp, sz]
@@ -326,6 +330,13 @@ class Encoder:
         st = ScreenStats()
         _check(lib().mi355_jpeg_screen_stats(self._h, stream, C.byref(st), int(reset)))
         return st.second_looks, st.exact_units
+
+    def walk_stats(self, reset=False, stream=0):
+        """(units whose AC string was coded a second time straight into device memory, passes in the general walk
+        loop) since creation / the last reset."""
+        st = ScreenStats()
+        _check(lib().mi355_jpeg_screen_stats(self._h, stream, C.byref(st), int(reset)))
+        return st.rewalked_units, st.general_passes
 
     def last_timings(self):
         t = Timings()

@@ -21,6 +21,10 @@ struct Geom {
     uint64_t frame_stride;  // bytes between frames = W*H*3
 };
 inline bool is420(const Geom& g) { return g.passes == 6; }
+// Per-frame verdicts in the bit-count array of a call (include/mi355_jpeg.h: MI355_BITS_*): no output for the frame.
+constexpr uint64_t kBitsCapacity = ~0ull;  // the scan does not fit the frame's output slot
+constexpr uint64_t kBitsCategory = ~1ull;  // a coefficient without a code in the tables
+constexpr uint64_t kBitsFlagged = ~1ull;   // >= this: one of the above
 // units (8x8 blocks in the scan) per frame
 inline size_t unit_count(const Geom& g) { return (size_t)g.N * g.passes; }
 
@@ -31,6 +35,7 @@ inline size_t unit_off_words(const Geom& g) { return (size_t)g.tiles * 192; }
 // Device pointers of the screened (integer-MFMA) pipeline, jpeg_screen_kernels.hip.
 struct ScreenParams {
     const uint4* afrag;     // [4 row tiles][5 digits][64 lanes] 16 int8: MFMA A fragments of the fixed-point map
+    const uint4* afrag_h;   // strict mode's first look: [4 row tiles][digit 1, 0][K half 0, 1][64 lanes] 8 f16 (integer-valued): MFMA A fragments
     const uint4* csc_frag;  // standard mode: [28 sets][64 lanes] 16 int8: MFMA A fragments of the colour conversion (jpeg_tables.h)
     const double* qconst;   // [2 channel types][64 zig-zag positions][4] = {s1, thr1, s2, thr2}
     const float* qconst_f;  // [2][16 groups of 4 positions][8] = {2^-23/Q x4, first-look threshold x4}
@@ -44,7 +49,7 @@ struct ScreenParams {
     uint32_t region_words;  // private region of each persistent wave (bump-allocated without atomics)
     uint32_t overflow_base; // first word of the shared overflow pool (= grid * region_words)
     uint32_t* counters;     // [0] overflow-pool words used
-    unsigned long long* stats;  // [0] second looks (wave-level groups), [1] units recomputed by the exact chain
+    unsigned long long* stats;  // [0] second looks (wave-level groups), [1] units recomputed by the exact chain, [2] units walked twice, [3] general-loop passes
     uint32_t prio_from_wg;  // k_screen_encode: workgroups >= this raise their issue priority (0xFFFFFFFF: none)
     uint32_t stagger;       // k_screen_encode: those workgroups start this many s_sleep(127) (~3.4 us each) late (0: none)
     uint32_t* status;

@@ -251,9 +251,10 @@ __global__ void __launch_bounds__(NT)
         to[g.tiles] = carry;
         const bool over = ((carry + 31) >> 5) * 4 > out_stride;
         if (over) atomicOr(status, 2u);  // MI355_E_CAPACITY
-        // Per-frame verdict: a frame that does not fit, or with a poisoned tile total (a size without a code, arena
-        // exhausted), gets the bit count ~0 and is skipped by the merge; the other frames of the call are complete and valid.
-        frame_bits[frame] = (flag_frames && (over || s_poison)) ? ~0ull : carry;
+        // Per-frame verdict: a frame with a poisoned tile total (a coefficient without a code) gets the bit count
+        // kBitsCategory, one that does not fit its output slot kBitsCapacity; both are skipped by the merge, the other
+        // frames of the call are complete and valid.
+        frame_bits[frame] = !flag_frames ? carry : (s_poison ? kBitsCategory : (over ? kBitsCapacity : carry));
         // the screened pipeline's arena counter is consumed by now: re-arm it
         if (reset_counters && frame == 0) reset_counters[0] = 0;
     }
@@ -343,7 +344,7 @@ __global__ void __launch_bounds__(1024)
         if (over) atomicOr(status, 2u);  // MI355_E_CAPACITY
         uint64_t poison = 0;  // see k_tile_scan
         for (uint32_t k = 0; k < chunks; ++k) poison |= ct[k];
-        frame_bits[frame] = (flag_frames && (over || (poison >> 63))) ? ~0ull : total;
+        frame_bits[frame] = !flag_frames ? total : ((poison >> 63) ? kBitsCategory : (over ? kBitsCapacity : total));
         if (reset_counters && frame == 0) reset_counters[0] = 0;
     }
 }

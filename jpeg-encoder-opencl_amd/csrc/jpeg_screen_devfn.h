@@ -19,6 +19,9 @@ typedef int16_t __attribute__((may_alias)) i16a;
 #endif
 
 constexpr uint32_t kSlotWordsFull = 54;  // worst case 63*(17+10)+4 = 1705 bits
+#ifndef MI355_SLOT_ROWS
+#define MI355_SLOT_ROWS 24
+#endif
 
 // Zig-zag rows of a wave's 64 units in LDS: int16, laid out [position 0..64][unit].  Unit u's
 // coefficient at a position sits at int16 index pos * 64 + row_unit_off(u): units 0..31 use the low
@@ -179,7 +182,9 @@ __device__ __forceinline__ void convert_rowpair(const uint32_t (&w)[12], bool av
                     const uint32_t y = div1000(s);
                     val[r][x] = y;
                     rgs[xx] = rg, bs[xx] = b;
-                    rem[xx] = s - __umul24(y, 1000u);
+                    // s - 1000 y as ONE 24-bit multiply-add (left to itself the compiler forms it with a quarter-rate
+                    // v_mad_u64_u32 and a v_bfe in front)
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(rem[xx]) : "v"(y), "s"(-1000), "v"(s));
                 } else {
                     val[r][x] = csc_packed<STD>(CHAN, rg, b);
                 }
@@ -431,39 +436,49 @@ static_assert((kRowSentinel + 32) * kLut2Cols + kRunNone == 65 * kLut2Cols, "exh
 constexpr uint32_t kLut2Miss = 31u;
 
 // Left-aligned 32-bit bit packer.  e = symbol bits left-aligned | length (<= 27) in bits 4..0.
-// Every put stores the word being filled (a later put to the same word overwrites it).
+// Every put stores the word being filled (a later put to the same word overwrites it).  The packer keeps the POSITION
+// of that word in the store's own units (Store::kStep per word: an LDS byte address for StoreLds, a word index for
+// StoreGlobal), so that the store needs one clamp and no address arithmetic per symbol.
 template <typename Store>
 struct Packer32 {
     uint32_t acc = 0;  // pending bits, left-aligned
     uint32_t n = 0;    // pending count, 0..31
-    uint32_t w = 0;    // completed words
+    uint32_t pos;      // position of the word being filled
     Store st;
-    __device__ __forceinline__ explicit Packer32(Store s) : st(s) {}
+    __device__ __forceinline__ explicit Packer32(Store s) : pos(s.first()), st(s) {}
     __device__ __forceinline__ void put(uint32_t e) {
         const uint32_t ml = e & ~31u, t = e & 31u;
         const uint32_t hi = acc | (ml >> n);
         const uint32_t lo = __builtin_amdgcn_alignbit(ml, 0u, n);  // ml << (32-n), and 0 when n == 0
         const uint32_t n2 = n + t;
-        st(w, hi);
+        st(pos, hi);
         const bool adv = n2 >= 32u;
         acc = adv ? lo : hi;
-        w += n2 >> 5;
+        pos += (n2 >> 5) * Store::kStep;
         n = n2 & 31u;
     }
-    __device__ __forceinline__ void finish() { st(w, acc); }
-    __device__ __forceinline__ void reset() { acc = 0, n = 0, w = 0; }
-    __device__ __forceinline__ uint32_t bits() const { return w * 32u + n; }
-    __device__ __forceinline__ uint32_t words() const { return w + (n ? 1u : 0u); }
+    __device__ __forceinline__ void finish() { st(pos, acc); }
+    __device__ __forceinline__ void reset() { acc = 0, n = 0, pos = st.first(); }
+    __device__ __forceinline__ uint32_t done() const { return (pos - st.first()) / Store::kStep; }  // completed words
+    __device__ __forceinline__ uint32_t bits() const { return done() * 32u + n; }
+    __device__ __forceinline__ uint32_t words() const { return done() + (n ? 1u : 0u); }
 };
 
-struct StoreLds {  // [word][lane]: `rows` words per unit; later words of an oversized string land in a dump word
-    uint32_t* slot;  // this lane's column
-    uint32_t rows;   // words per unit that are kept
-    uint32_t dump;   // word offset (from slot) of this lane's dump word
-    __device__ __forceinline__ void operator()(uint32_t w, uint32_t v) const { slot[w < rows ? w * 64u : dump] = v; }
+typedef __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+struct StoreLds {  // [word][lane]: kSlotRows words per unit are kept; later words of an oversized string land in the dump row
+    static constexpr uint32_t kStep = 256;  // LDS bytes from one word of a unit to the next (64 lanes)
+    uint32_t base;                          // LDS byte address of this lane's column
+    __device__ __forceinline__ explicit StoreLds(uint32_t* col) : base((uint32_t)(uintptr_t)(lds_u32_ptr)col) {}
+    __device__ __forceinline__ uint32_t first() const { return base; }
+    __device__ __forceinline__ void operator()(uint32_t pos, uint32_t v) const {
+        const uint32_t lim = base + MI355_SLOT_ROWS * kStep;  // the dump row
+        *(lds_u32_ptr)(uintptr_t)(pos < lim ? pos : lim) = v;
+    }
 };
 struct StoreGlobal {  // lane-private run of kSlotWordsFull words
+    static constexpr uint32_t kStep = 1;
     uint32_t* dst;
+    __device__ __forceinline__ uint32_t first() const { return 0u; }
     __device__ __forceinline__ void operator()(uint32_t w, uint32_t v) const {
         dst[w < kSlotWordsFull - 1 ? w : kSlotWordsFull - 1] = v;
     }
@@ -658,7 +673,9 @@ __device__ __forceinline__ bool walk_nonzeros(const i16a* row, uint64_t mask, co
 // In fp32: t = acc3 * 256 + acc2 (|t| < 2^28.1, its conversion is off by <= 2^4.1), acc4 converts exactly,
 // fv = fma(acc4, 2^16, fl(t)), zf = fl(fv * fl(2^-23/Q)): three roundings, |zf - Y' 2^-23/Q| <= |z| 2^-22 +
 // 2^-18/Q.  rn = nearest integer of zf by the 1.5 * 2^23 trick, d = zf - rn exact.  The quantised value is
-// rn whenever |d| + |zf| 2^-21 < 0.5 - (E1_R + 2^-18 + delta_R)/Q - 2^-22  (threshold rounded down on the host).
+// rn whenever |d| + |zf| 2^-21 < 0.5 - (E1_R + 2^-18 + delta_R)/Q - 2^-22; the kernel tests the stronger
+// d^2 < thr_R^2 with thr_R = 0.5 - (E1_R + 2^-18 + delta_R)/Q - 2^-22 - 2^-21 max|zf| over the row's inputs
+// (max|zf| <= 128 sum_i |Lt3[R][i]| / Q (1 + 2^-20)), thr_R^2 rounded down on the host.
 // Second look (wave-uniform, 0.2 % of the groups on q50 noise): the two low digits are fetched and all five
 // give y2 = Lt p exactly in fp64; threshold 0.5 - delta_R/Q (1 + 1e-6) - 2^-38.  Standard mode is DEFINED by
 // its integer map and decides exactly there.  What is still undecided sets `amb`: the exact ordered fp64
@@ -709,17 +726,21 @@ __device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], con
         return;
     }
     const v2f rA = aA - M2, rB = aB - M2;
-    const v2f dA = zA - rA, dB = zB - rB;
-    const float zz[4] = {zA[0], zA[1], zB[0], zB[1]};
-    const float dd[4] = {dA[0], dA[1], dB[0], dB[1]};
-    bool a1[4];
+    const v2f dA = zA - rA, dB = zB - rB;  // exact: zf and its nearest integer are within 1/2 of each other
+    // Accept test |d| < thr as thr^2 - d^2 > 0: one packed fma per pair of positions (the sign of an fma's exact value
+    // survives its rounding), the smallest of the four by a three-input minimum, ONE compare per lane.  thr^2 comes from the
+    // host rounded DOWN and already carries the |zf| 2^-21 term at the row's largest |zf|.
+    const v2f hA = {qf[4], qf[5]}, hB = {qf[6], qf[7]};
+    const v2f tA = __builtin_elementwise_fma(-dA, dA, hA), tB = __builtin_elementwise_fma(-dB, dB, hB);
+    float tt[4] = {tA[0], tA[1], tB[0], tB[1]};
+    if (mt == 0 && gq == 0) tt[0] = 1.0f;  // coefficient 0: overwritten by the caller, never judged here
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        qb[r] = __float_as_uint(aa[r]);  // 0x4B400000 + q
-        a1[r] = !(__builtin_fmaf(__builtin_fabsf(zz[r]), 0x1p-21f, __builtin_fabsf(dd[r])) < qf[4 + r]);
-        if (mt == 0 && r == 0 && gq == 0) a1[r] = false;  // coefficient 0: overwritten by the caller
-    }
-    if (wave_any(a1[0] || a1[1] || a1[2] || a1[3])) {
+    for (int r = 0; r < 4; ++r) qb[r] = __float_as_uint(aa[r]);  // 0x4B400000 + q
+    const float tmin = __builtin_fminf(__builtin_fminf(__builtin_fminf(tt[0], tt[1]), tt[2]), tt[3]);
+    if (wave_any(!(tmin > 0.0f))) {
+        bool a1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1[r] = !(tt[r] > 0.0f);
         if (lane == 0) atomicAdd(&sp.stats[0], 1ull);
         const uint4 t1 = sp.afrag[(mt * kScreenLimbs + 1) * 64 + lane], t0 = sp.afrag[(mt * kScreenLimbs) * 64 + lane];
         const v4i acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w}, B,
@@ -741,6 +762,104 @@ __device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], con
                     qb[r] = (uint32_t)(z < 0.0 ? -nn : nn);
                     amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
                 }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Strict mode's first look on the f16 matrix instruction (round 4): the fixed-point map as TWO digits of 11 bits,
+//     Lt39 = D1 2^28 + D0 2^17 + rho,   |D1| < 2^11, |D0| <= 2^10, |rho| <= 2^16   (host: upload_afrag_f16),
+// both held as INTEGER-valued f16 (exact), against the samples - 128 as f16 (exact).  v_mfma_f32_16x16x32_f16 forms
+// sum_k A[i][k] B[k][j] in fp32; every product and every partial sum of a row is an integer below 2^24 in magnitude
+// (|sum D1 p| <= 128 sum |D1| < 2^21.1 because the rows' 1-norms are <= 8; |sum D0 p| <= 64 2^10 2^7 = 2^23), hence
+// representable, hence the accumulators hi = sum D1 p and lo = sum D0 p are EXACT whatever order and internal
+// rounding the unit uses (tests/test_screen_pinning.py::test_f16_matrix_accumulators_are_exact checks the hardware
+// on adversarial and random blocks through mi355_jpeg_selftest_look).  Y = hi 2^11 + lo = (Lt39 - rho) p / 2^17, so
+//     c/Q = Y 2^-22 / Q + e,  |e| <= (E1_R + delta_R)/Q,  E1_R = 128 sum_i |rho[R][i]| 2^-39 <= 2^-10.
+// In fp32: fv = fma(hi, 2^11, lo) (one rounding), zf = fl(fv fl(2^-22/Q)): |zf - Y 2^-22/Q| <= |z| 2^-22, covered by
+// 2^-21 max|zf| in the threshold.  No integer -> float conversions and no digit recombination on the VALU: two
+// packed fmas per four positions where the int8 form needs four shift-adds, eight conversions and two packed fmas.
+// The second look is the int8 one (all five base-256 digits, fetched on demand) -- it decides as before.
+// ----------------------------------------------------------------------------
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int kLookFragsF16 = 4;  // [digit 1, digit 0] x [K half 0, 1]
+
+__device__ __forceinline__ void load_look_fragments_f16(const ScreenParams& sp, uint32_t lane, v4i (&A)[4][kLookFragsF16]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int l = 0; l < kLookFragsF16; ++l) {
+            const uint4 t = sp.afrag_h[(mt * kLookFragsF16 + l) * 64 + lane];
+            A[mt][l] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+        }
+}
+
+// 16 samples (unsigned bytes, 4 per dword, sample order) -> sample - 128 as f16: K half h = row 2 gq + h of the block.
+// 0x6400 | b is the f16 1024 + b; subtracting 1152 is exact.
+__device__ __forceinline__ void samples_to_f16(const uint32_t (&pk)[4], v4i (&Bh)[2]) {
+    const v2h kShift = {(_Float16)-1152.0f, (_Float16)-1152.0f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t x = __builtin_amdgcn_perm(0x64646464u, pk[2 * h + (i >> 1)], (i & 1) ? 0x04030402u : 0x04010400u);
+            w[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2h, x) + kShift);
+        }
+        Bh[h] = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    }
+}
+
+__device__ __forceinline__ void screen_quantise_f16(const v4i (&A)[kLookFragsF16], const v4i (&Bh)[2], const uint32_t (&pk)[4],
+                                                    const ScreenParams& sp, const float* __restrict__ qf /* LDS: sf[4], thr^2[4] */,
+                                                    uint32_t ct, int mt, uint32_t gq, uint32_t lane, uint32_t (&qb)[4], bool& amb) {
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    const v8h b0 = __builtin_bit_cast(v8h, Bh[0]), b1 = __builtin_bit_cast(v8h, Bh[1]);
+    v4f hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, A[0]), b0, zero, 0, 0, 0);
+    v4f lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, A[2]), b0, zero, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, A[1]), b1, hi, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, A[3]), b1, lo, 0, 0, 0);
+    const v2f k2048 = {2048.0f, 2048.0f};
+    const v2f fA = __builtin_elementwise_fma(v2f{hi[0], hi[1]}, k2048, v2f{lo[0], lo[1]});
+    const v2f fB = __builtin_elementwise_fma(v2f{hi[2], hi[3]}, k2048, v2f{lo[2], lo[3]});
+    const v2f sA = {qf[0], qf[1]}, sB = {qf[2], qf[3]};
+    const v2f M2 = {12582912.0f, 12582912.0f};
+    const v2f zA = fA * sA, zB = fB * sB;
+    const v2f aA = zA + M2, aB = zB + M2;
+    const v2f rA = aA - M2, rB = aB - M2;
+    const v2f dA = zA - rA, dB = zB - rB;  // exact: zf and its nearest integer are within 1/2 of each other
+    const v2f hA = {qf[4], qf[5]}, hB = {qf[6], qf[7]};
+    const v2f tA = __builtin_elementwise_fma(-dA, dA, hA), tB = __builtin_elementwise_fma(-dB, dB, hB);
+    float tt[4] = {tA[0], tA[1], tB[0], tB[1]};
+    if (mt == 0 && gq == 0) tt[0] = 1.0f;  // coefficient 0: overwritten by the caller, never judged here
+    qb[0] = __float_as_uint(aA[0]), qb[1] = __float_as_uint(aA[1]), qb[2] = __float_as_uint(aB[0]), qb[3] = __float_as_uint(aB[1]);
+    const float tmin = __builtin_fminf(__builtin_fminf(__builtin_fminf(tt[0], tt[1]), tt[2]), tt[3]);
+    if (wave_any(!(tmin > 0.0f))) {
+        if (lane == 0) atomicAdd(&sp.stats[0], 1ull);
+        // second look: all five base-256 digits on the int8 instruction, exact in fp64
+        const v4i B = v4i{(int)(pk[0] ^ 0x80808080u), (int)(pk[1] ^ 0x80808080u), (int)(pk[2] ^ 0x80808080u), (int)(pk[3] ^ 0x80808080u)};
+        v4i acc[kScreenLimbs];
+#pragma unroll
+        for (int l = 0; l < kScreenLimbs; ++l) {
+            const uint4 t = sp.afrag[(mt * kScreenLimbs + l) * 64 + lane];
+            acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w}, B, v4i{0, 0, 0, 0}, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!(tt[r] > 0.0f)) {
+                // {s1, thr1, s2, thr2} of this position: read from memory, the second look is rare
+                const double* qc = sp.qconst + ((size_t)ct * 64 + 16 * mt + 4 * gq + r) * 4;
+                const double y1 = (double)acc[4][r] * 65536.0 + (double)(acc[3][r] * 256 + acc[2][r]);  // exact (< 2^37)
+                const double y2 = y1 * 65536.0 + (double)(acc[1][r] * 256 + acc[0][r]);                  // exact (< 2^53)
+                const double z = y2 * qc[2];
+                const double ta = __builtin_fabs(z) + 0.5;
+                const double fr = ta - __builtin_floor(ta);
+                const int nn = (int)ta;
+                qb[r] = (uint32_t)(z < 0.0 ? -nn : nn);
+                amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
             }
         }
     }

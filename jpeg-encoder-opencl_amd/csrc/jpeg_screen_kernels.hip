@@ -54,8 +54,21 @@ constexpr uint32_t kEncWaves = 4;
 // MODE 0: strict (the reference's arithmetic); 1: standard 4:4:4; 2: standard 4:2:0 (tile = 64 MCUs,
 // six passes: luma quarter-tiles 0..3 -- unit u of pass s is block k = u & 3 of MCU 16 s + u / 4, i.e.
 // the scan order of the luma blocks -- then Cb, Cr with one block per MCU).
+// At most 224 registers (the attribute counts in units of two on gfx90a and later: 112): two workgroups of this kernel per CU leave 64 per SIMD lane, which is what the tail kernels of the
+// part in front need to run BESIDE it (k_merge: two waves of 32 on a SIMD; above 224 batched calls lose a fifth).
+#ifndef MI355_VGPR_CAP
+#define MI355_VGPR_CAP 112
+#endif
+#ifndef MI355_LOOK_F16
+#define MI355_LOOK_F16 1
+#endif
+#if MI355_VGPR_CAP
+#define MI355_CAP_ATTR __attribute__((amdgpu_num_vgpr(MI355_VGPR_CAP)))
+#else
+#define MI355_CAP_ATTR
+#endif
 template <bool PROBE, int MODE>
-__global__ void __launch_bounds__(256, 2)
+MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
     k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
     constexpr bool STD = MODE != 0, S420 = MODE == 2;
     constexpr uint32_t kPasses = S420 ? 6u : 3u;
@@ -88,8 +101,12 @@ __global__ void __launch_bounds__(256, 2)
     i16a* const tb16 = reinterpret_cast<i16a*>(s_tbuf);
     // A fragments of the top three digits stay in registers; the two low digits only matter for the
     // (rare) second look and are fetched on demand.
-    v4i A[4][kLookDigits];
-    load_look_fragments(sp, lane, A);
+    // (strict: the f16 form of the first look, two digits x two K halves; standard: the int8 form, three digits)
+    constexpr bool kI8 = STD || !MI355_LOOK_F16;
+    constexpr int kFrags = kI8 ? kLookDigits : kLookFragsF16;
+    v4i A[4][kFrags];
+    if constexpr (kI8) load_look_fragments(sp, lane, A);
+    else load_look_fragments_f16(sp, lane, A);
     // quantiser divisors of coefficient 0, read once: a load per pass would sit behind everything the wave has in flight
     // (vmcnt retires in issue order), the next pass's first rows included
     const double q0_luma = sp.qd[0], q0_chroma = sp.qd[64];
@@ -122,13 +139,15 @@ __global__ void __launch_bounds__(256, 2)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
     bool walk_general[2] = {false, false};  // per channel type: the last pass had a symbol-table miss (walk_nonzeros)
+    uint32_t n_rewalked = 0, n_general = 0;  // mi355_jpeg_screen_stats: summed per wave, added once at the end (one
+                                             // atomic per pass on one address would serialise the whole device at q90)
     // One pass = one (frame, tile, pass) of this wave's share.  Its coordinates are worked out one pass AHEAD, and the
     // first row pair of the next pass is requested before the entropy walk of the current one: the load (an HBM miss for
     // the first of a tile's three channel waves) lands during the walk instead of stalling the next pass at its first
     // instruction, and because vmcnt retires in issue order it does not wait behind this pass's scattered string stores.
     struct Pass {
         uint32_t frame, tile, chan;
-        uint32_t bxs[4], bys[4];
+        uint32_t bxy[4];  // block (or MCU) coordinates of this lane's four units: x | y << 16 (packed: registers)
         bool fast;
     };
     auto locate = [&](uint32_t p) -> Pass {
@@ -153,7 +172,7 @@ __global__ void __launch_bounds__(256, 2)
         bool interior = true;
         if constexpr (S420) {
             // MCU of this lane's unit in sub-tile j: luma pass s: 16 s + 4 j + n / 4 (block k = n & 3 of it),
-            // chroma pass: 16 j + n.  For chroma passes bxs/bys hold MCU coordinates.
+            // chroma pass: 16 j + n.  For chroma passes bxy holds MCU coordinates.
             const uint32_t step = luma420 ? 4u : 16u;
             uint32_t m = tile * 64 + (luma420 ? 16 * chan + (n >> 2) : n);
             uint32_t my = m / g.nmx, mx = m - my * g.nmx;
@@ -164,12 +183,11 @@ __global__ void __launch_bounds__(256, 2)
                     my = g.N / g.nmx - 1;
                 }
                 if (luma420) {
-                    ps.bxs[j] = 2 * mx + (n & 1);
-                    ps.bys[j] = 2 * my + ((n >> 1) & 1);
-                    interior = interior && (ps.bxs[j] * 8 + 8 <= g.W) && (ps.bys[j] * 8 + 8 <= g.H);
+                    const uint32_t lx = 2 * mx + (n & 1), ly = 2 * my + ((n >> 1) & 1);
+                    ps.bxy[j] = lx | (ly << 16);
+                    interior = interior && (lx * 8 + 8 <= g.W) && (ly * 8 + 8 <= g.H);
                 } else {
-                    ps.bxs[j] = mx;
-                    ps.bys[j] = my;
+                    ps.bxy[j] = mx | (my << 16);
                     interior = interior && (mx * 16 + 16 <= g.W) && (my * 16 + 16 <= g.H);
                 }
                 m += step;
@@ -189,8 +207,7 @@ __global__ void __launch_bounds__(256, 2)
                     bx = g.nbx - 1;
                     by = g.N / g.nbx - 1;
                 }
-                ps.bxs[j] = bx;
-                ps.bys[j] = by;
+                ps.bxy[j] = bx | (by << 16);
                 interior = interior && (bx * 8 + 8 <= g.W) && (by * 8 + 8 <= g.H);
                 bx += 16;
                 while (bx >= g.nbx) {
@@ -214,9 +231,9 @@ __global__ void __launch_bounds__(256, 2)
             // the pass's colour-conversion fragments travel with its first rows: requested before the walk of the pass in
             // front, they do not queue behind that pass's string stores (vmcnt retires in issue order)
             load_csc_fragments(sp, lane, (int)ps.chan * 4, F);
-            load_std_rowpair(pf, g, ps.bxs[0], ps.bys[0], gq, Xn);
+            load_std_rowpair(pf, g, ps.bxy[0] & 0xffffu, ps.bxy[0] >> 16, gq, Xn);
         } else {
-            if (!chroma420) load_raw_rowpair(pf, g, ps.bxs[0], ps.bys[0], gq, raw);
+            if (!chroma420) load_raw_rowpair(pf, g, ps.bxy[0] & 0xffffu, ps.bxy[0] >> 16, gq, raw);
         }
     };
     Pass cur{}, nxt{};
@@ -234,9 +251,6 @@ __global__ void __launch_bounds__(256, 2)
         const uint8_t* f = rgb + (size_t)frame * g.frame_stride;
         const bool avg = !STD && (comp != 0) && (g.flags & 1u);  // standard mode never replicates chroma means
         const size_t us_base = (((size_t)frame * g.tiles + tile) * kPasses + chan) * 64;
-        uint32_t bxs[4], bys[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bxs[j] = cur.bxs[j], bys[j] = cur.bys[j];
         const bool fast = cur.fast;
 
         STAMP(0);
@@ -260,14 +274,14 @@ __global__ void __launch_bounds__(256, 2)
         uint32_t dcsum = 0;  // sample sum of the block whose coefficient 0 this lane will form
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t bx = bxs[j], by = bys[j];
+            const uint32_t bx = cur.bxy[j] & 0xffffu, by = cur.bxy[j] >> 16;
             uint32_t pk[4];  // 16 samples; on_mfma: as sample - 128 (int8), else unsigned
             if (on_mfma) {
                 if constexpr (kCscMfma) {
                     // (one buffer: the next row pair lands during the quantiser)
                     if (comp) std_rowpair_mfma<true>(Xn, F, pk);
                     else std_rowpair_mfma<false>(Xn, F, pk);
-                    if (j < 3) load_std_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, Xn);
+                    if (j < 3) load_std_rowpair(f, g, cur.bxy[j + 1] & 0xffffu, cur.bxy[j + 1] >> 16, gq, Xn);
                 }
             } else if (chroma420) {
                 if constexpr (S420) {  // rows 2gq, 2gq+1 of the MCU's 8x8 chroma block <- pixel rows 4gq .. 4gq+3
@@ -286,13 +300,13 @@ __global__ void __launch_bounds__(256, 2)
                     }
                 }
             } else if (fast) {
-                uint32_t cur[12];
+                uint32_t rp[12];
 #pragma unroll
-                for (int i = 0; i < 12; ++i) cur[i] = raw[i];
-                if (j < 3) load_raw_rowpair(f, g, bxs[j + 1], bys[j + 1], gq, raw);  // (two pairs in flight: -1 %)
-                if (comp == 0) convert_rowpair<0, STD>(cur, false, pk);
-                else if (comp == 1) convert_rowpair<1, STD>(cur, avg, pk);
-                else convert_rowpair<2, STD>(cur, avg, pk);
+                for (int i = 0; i < 12; ++i) rp[i] = raw[i];
+                if (j < 3) load_raw_rowpair(f, g, cur.bxy[j + 1] & 0xffffu, cur.bxy[j + 1] >> 16, gq, raw);  // (two pairs in flight: -1 %)
+                if (comp == 0) convert_rowpair<0, STD>(rp, false, pk);
+                else if (comp == 1) convert_rowpair<1, STD>(rp, avg, pk);
+                else convert_rowpair<2, STD>(rp, avg, pk);
             } else {
                 if (comp == 0) generic_rowpair<0, STD>(f, g, false, bx, by, gq, pk);
                 else if (comp == 1) generic_rowpair<1, STD>(f, g, avg, bx, by, gq, pk);
@@ -312,6 +326,8 @@ __global__ void __launch_bounds__(256, 2)
             // sum of the block's 64 samples (for the exact DC): 16 in this lane, then over the 4 row-pair lanes
             uint32_t ssum = 0;
             v4i B;
+            v4i Bh[2];  // strict: the same samples as f16, per K half
+            if constexpr (!kI8) samples_to_f16(pk, Bh);
             if (on_mfma) {  // signed bytes already: the sum of the unsigned samples is 16 * 128 more
                 int sg = 2048;
 #pragma unroll
@@ -337,7 +353,8 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 uint32_t qb[4];  // low 16 bits = quantised value
-                screen_quantise<STD>(A[mt], B, sp, &s_qf[ct][4 * mt + gq][0], ct, mt, gq, lane, qb, amb);
+                if constexpr (kI8) screen_quantise<STD>(A[mt], B, sp, &s_qf[ct][4 * mt + gq][0], ct, mt, gq, lane, qb, amb);
+                else screen_quantise_f16(A[mt], Bh, pk, sp, &s_qf[ct][4 * mt + gq][0], ct, mt, gq, lane, qb, amb);
                 // zig-zag positions 16mt+4gq .. +3 of unit 16j+n -> transpose buffer + non-zero bits
                 i16a* row = tb16 + (16 * mt + 4 * gq) * 64 + row_unit_off(16 * j + n);
 #pragma unroll
@@ -360,6 +377,9 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) qprev[r] = qb[r];
                 }
+#ifdef MI355_SCHED_FENCE
+                __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: without it the scheduler overlaps them up to the register limit
+#endif
             }
             atomicOr(&s_mlo[16 * j + n], (nzlo << (4 * gq)) & ~1u);
             atomicOr(&s_mhi[16 * j + n], nzhi << (4 * gq));
@@ -417,10 +437,11 @@ __global__ void __launch_bounds__(256, 2)
                 dst[pp * 64] = active ? (((uint32_t)(uint16_t)row16[2 * pp * 64]) | ((uint32_t)(uint16_t)row16[(2 * pp + 1) * 64] << 16)) : 0u;
         }
 
-        Packer32<StoreLds> pkr(StoreLds{&s_slot[lane], kSlotRows, kSlotRows * 64u});
+        Packer32<StoreLds> pkr(StoreLds{&s_slot[lane]});
         mask = mark_zero_runs(mask);  // ZRL positions become virtual non-zeros (after the probe dump above)
         const uint32_t maxcnt = wave_max((uint32_t)__popcll(mask));
         bool ok = walk_nonzeros<STD>(row16, mask, s_lut2[ct], s_act[ct], pkr, maxcnt, walk_general[ct]);
+        n_general += walk_general[ct] ? 1u : 0u;
         const uint32_t aclen = pkr.bits();
         uint32_t nw = pkr.words();
         STAMP(2);
@@ -434,35 +455,38 @@ __global__ void __launch_bounds__(256, 2)
         // block of the same channel: the neighbouring lane.  Lane 0's predecessor is the last block
         // of the previous tile, which another wave owns: its DC symbol is left out here and added
         // by k_dc_heads from the DCs in `meta`.  Tile sums are accumulated with one atomic per wave.
+        uint32_t ubits = aclen;
         {
             const int pred = __shfl_up(dc, 1);
-            uint32_t ubits = aclen;
             auto count = [&](uint32_t, uint32_t len) { ubits += len; };
             const bool dc_ok = lane == 0 || put_dc(dc - pred, s_dc[ct], count);
             if (!dc_ok && active) atomicOr(sp.status, 1u), POISON_TILE();  // MI355_E_CATEGORY
             if (!active) ubits = 0;
-            ubits = wave_sum(ubits);
-            if (lane == 0 && ubits) atomicAdd(&sp.tile_bits[(size_t)frame * g.tiles + tile], ubits);
         }
-
         STAMP(3);
-        // arena space: regular strings back to back; oversized ones get a full-size private run
+        // arena space: regular strings back to back; oversized ones get a full-size private run.  ONE wave scan carries
+        // both sums: the units' bits (< 2^11 each) in the low 20 bits, the words needed (<= 54 each) above them.
         const uint32_t need = oversize && nw ? kSlotWordsFull : nw;
-        const uint32_t incl = wave_incl_scan(need, lane);
-        const uint32_t base = wa.take(sp, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), lane);
+        const uint32_t both = wave_incl_scan((need << 20) | ubits, lane);
+        const uint32_t both_all = (uint32_t)__builtin_amdgcn_readlane((int)both, 63);
+        if (lane == 0 && (both_all & 0xFFFFFu)) atomicAdd(&sp.tile_bits[(size_t)frame * g.tiles + tile], both_all & 0xFFFFFu);
+        const uint32_t incl = both >> 20;
+        const uint32_t base = wa.take(sp, both_all >> 20, lane);
         const uint32_t off = base + incl - need;
         const bool fits = base != 0xFFFFFFFFu;
         if (!fits) {
-            // MI355_E_CAPACITY (strings beyond 9/4 of the output capacity: the output could not hold them either)
-            if (lane == 0) atomicOr(sp.status, 2u), POISON_TILE();
+            // cannot happen: the overflow pool holds the worst case of every unit of the part (run_screened).  MI355_E_INTERNAL.
+            if (lane == 0) atomicOr(sp.status, 4u), POISON_TILE();
         } else {
             const uint32_t ncopy = oversize ? 0u : nw;
 #pragma unroll
             for (uint32_t w = 0; w < 8; ++w)
                 if (w < ncopy) sp.arena[off + w] = s_slot[w * 64 + lane];
-            for (uint32_t w = 8; __any(w < ncopy); ++w)
+            for (uint32_t w = 8; wave_any(w < ncopy); ++w)
                 if (w < ncopy) sp.arena[off + w] = s_slot[w * 64 + lane];
-            if (__any(oversize && nw)) {  // rare: string longer than the LDS slot: walk again, straight to memory
+            const uint64_t again = __ballot(oversize && nw);
+            if (again) {  // string longer than the LDS slot (q50: never; noise at q90: most luma units): walk again, straight to memory
+                n_rewalked += (uint32_t)__popcll(again);
                 if (oversize && nw) {
                     Packer32<StoreGlobal> pg(StoreGlobal{sp.arena + off});
                     bool gen = true;
@@ -475,6 +499,8 @@ __global__ void __launch_bounds__(256, 2)
         STAMP(4);
         cur = nxt;
     }
+    if (lane == 0 && n_rewalked) atomicAdd(&sp.stats[2], (unsigned long long)n_rewalked);
+    if (lane == 0 && n_general) atomicAdd(&sp.stats[3], (unsigned long long)n_general);
 #ifdef MI355_STAMPS
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wave_t1)::"memory");
     if (sp.stamps && lane == 0) {
@@ -561,9 +587,9 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
     __shared__ uint32_t s_words[kWindow];
     const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
     const uint32_t tile = blockIdx.x, frame = blockIdx.y;
-    // a frame with an error (k_tile_scan wrote its bit count as ~0: over capacity, a size without a code, arena
-    // exhausted) is skipped as a whole; the other frames of the call are written in full
-    if (frame_bits[frame] == ~0ull) return;
+    // a frame with an error (k_tile_scan wrote its verdict in place of the bit count: over capacity, a size without a
+    // code) is skipped as a whole; the other frames of the call are written in full
+    if (frame_bits[frame] >= kBitsFlagged) return;
     if (lds_words_limit > kWindow) lds_words_limit = kWindow;
     const size_t ft0 = (size_t)frame * g.tiles;
     const uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);

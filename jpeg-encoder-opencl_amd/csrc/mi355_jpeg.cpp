@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <system_error>
 #include <vector>
 
 #include <cmath>
@@ -22,6 +23,10 @@
 #include "jpeg_device.h"
 #include "jpeg_screen_tables.h"
 #include "jpeg_tables.h"
+
+#ifndef MI355_LOOK_F16
+#define MI355_LOOK_F16 1
+#endif
 
 using namespace mi355;
 
@@ -154,7 +159,7 @@ struct mi355_jpeg_ctx {
     uint32_t* d_counters = nullptr; // [64] arena overflow-pool words, one per part in flight
     uint32_t max_sets = 0;          // MI355_JPEG_MAX_SETS (tests): upper limit of the workspace sets of a batch (0 = none)
     uint32_t stagger = 0;           // MI355_JPEG_STAGGER (timing experiment, 0..64): later-dispatched workgroups start this many sleeps late
-    unsigned long long* d_stats = nullptr;  // [0] second looks, [1] exact units (mi355_jpeg_screen_stats)
+    unsigned long long* d_stats = nullptr;  // [0] second looks, [1] exact units, [2] rewalked units, [3] general-loop passes (mi355_jpeg_screen_stats)
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
     uint8_t* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // scratch of the stage-by-stage entry points
     size_t stage_cap[4] = {0, 0, 0, 0};
@@ -206,6 +211,22 @@ int ensure(T*& p, size_t& cap, size_t need, bool zero = false) {
     return MI355_OK;
 }
 
+// (strict mode's first look: see upload_afrag_f16)
+struct LookDigits {
+    int32_t d1, d0;
+    int64_t rho;
+};
+LookDigits split_look(int R, int i) {
+    int64_t v = 0;
+    for (int l = kScreenLimbs - 1; l >= 0; --l) v = v * 256 + kScreenLimb[l][R][i];
+    auto fdiv = [](int64_t a, int64_t b) { return (a >= 0 ? a : a - (b - 1)) / b; };  // floor division, b > 0
+    LookDigits d;
+    d.d1 = (int32_t)fdiv(v + (1ll << 27), 1ll << 28);
+    const int64_t r1 = v - (int64_t)d.d1 * (1ll << 28);
+    d.d0 = (int32_t)fdiv(r1 + (1ll << 16), 1ll << 17);
+    d.rho = r1 - (int64_t)d.d0 * (1ll << 17);
+    return d;
+}
 int upload_tables(mi355_jpeg_ctx* c) {
     // The copies below run on the null stream; encode calls run on the caller's (usually non-blocking)
     // streams, which do not order themselves against it in either direction.  Wait for everything in
@@ -253,8 +274,9 @@ int upload_tables(mi355_jpeg_ctx* c) {
     // the two low digits; zf = fl(fma(acc4, 2^16, fl(acc3 * 256 + acc2)) * sf), sf = fl(2^-23/Q).
     //   |c/Q - Y' 2^-23/Q| <= (E1_R + delta_R)/Q   (dropped digits: exact worst case per row; map + chain error)
     //   |zf - Y' 2^-23/Q|  <= |z| 2^-22 + 2^-18/Q   (three fp32 roundings; the conversion of acc3 * 256 + acc2)
-    // the first term of the second line is covered in the kernel by |zf| 2^-21; thr = 0.5 - tau - 2^-22 (float
-    // rounding of thr itself and of the test), rounded DOWN to float.  One set per map (strict / standard).
+    // the first term of the second line is covered by 2^-21 max|zf| (the row's largest |zf| over all inputs, from the
+    // table); thr = 0.5 - tau - 2^-22 - 2^-21 max|zf|, and the kernel tests d^2 < thr^2 (square rounded DOWN to float).
+    // One set per map (strict / standard).
     float qf[2][2][16][8];
     for (int m = 0; m < 2; ++m)
         for (int ct = 0; ct < 2; ++ct)
@@ -263,16 +285,39 @@ int upload_tables(mi355_jpeg_ctx* c) {
                     const int R = 16 * (grp >> 2) + 4 * (grp & 3) + r;
                     const double Q = (double)(ct ? c->qchrom[zz[R]] : c->qlum[zz[R]]);
                     const auto& limb = m ? kStdLimb : kScreenLimb;
-                    long s1 = 0, s0 = 0;
-                    for (int i = 0; i < 64; ++i) s1 += std::abs((int)limb[1][R][i]), s0 += std::abs((int)limb[0][R][i]);
-                    const double e1 = std::ldexp(128.0 * (256.0 * (double)s1 + (double)s0), -kScreenFracBits);
                     const double delta = kScreenEps[R] + kScreenFixErr;
+                    double e1, zmax;
+                    if (m == 0 && MI355_LOOK_F16) {
+                        // strict: the f16 first look (screen_quantise_f16): dropped part rho, kept part D1 2^11 + D0 in units of 2^-22
+                        double srho = 0, skept = 0;
+                        for (int i = 0; i < 64; ++i) {
+                            const LookDigits d = split_look(R, i);
+                            srho += std::fabs((double)d.rho);
+                            skept += std::fabs(2048.0 * d.d1 + (double)d.d0);
+                        }
+                        e1 = std::ldexp(128.0 * srho, -kScreenFracBits);
+                        zmax = std::ldexp(128.0 * skept, -22) / Q * 1.000002;
+                        qf[m][ct][grp][r] = (float)(std::ldexp(1.0, -22) / Q);
+                    } else {
+                        long s1 = 0, s0 = 0;
+                        for (int i = 0; i < 64; ++i) s1 += std::abs((int)limb[1][R][i]), s0 += std::abs((int)limb[0][R][i]);
+                        e1 = std::ldexp(128.0 * (256.0 * (double)s1 + (double)s0), -kScreenFracBits);
+                        double s3 = 0;
+                        for (int i = 0; i < 64; ++i)
+                            s3 += std::fabs(65536.0 * limb[4][R][i] + 256.0 * limb[3][R][i] + (double)limb[2][R][i]);
+                        zmax = std::ldexp(128.0 * s3, 16 - kScreenFracBits) / Q * 1.000002;
+                        qf[m][ct][grp][r] = (float)(std::ldexp(1.0, 16 - kScreenFracBits) / Q);
+                    }
+                    // |zf - (kept part) p / Q| <= |z| 2^-22 (+ 2^-18/Q for the int8 form's integer conversion): covered by 2^-21 max|zf|
                     const double tau = ((e1 + std::ldexp(1.0, -18) + delta) / Q * 1.000001) * c->tau_scale + std::ldexp(1.0, -22);
-                    qf[m][ct][grp][r] = (float)(std::ldexp(1.0, 16 - kScreenFracBits) / Q);
-                    // round the threshold DOWN to float
-                    float th = tau < 0.5 ? (float)(0.5 - tau) : -1.0f;
-                    if (tau < 0.5 && (double)th > 0.5 - tau) th = std::nextafterf(th, -1.0f);
-                    qf[m][ct][grp][4 + r] = th;
+                    const double thr = 0.5 - tau - std::ldexp(zmax, -21);
+                    // the kernel tests d^2 < thr^2: the square, rounded DOWN to float (negative: never accepted)
+                    float th2 = -1.0f;
+                    if (thr > 0.0) {
+                        th2 = (float)(thr * thr);
+                        if ((double)th2 > thr * thr) th2 = std::nextafterf(th2, -1.0f);
+                    }
+                    qf[m][ct][grp][4 + r] = th2;
                 }
     HIP_TRY(hipMemcpy(c->d_qconst_f, qf, sizeof qf, hipMemcpyHostToDevice));
     // Whole-symbol tables of the screened pipeline's unit walk: for run r and value v (|v| <= 31)
@@ -325,6 +370,35 @@ int upload_afrag(mi355_jpeg_ctx* c) {
                         h[m * kAfragBytes + (((size_t)mt * kScreenLimbs + l) * 64 + lane) * 16 + i] =
                             (m ? kStdLimb : kScreenLimb)[l][16 * mt + (lane & 15)][16 * (lane >> 4) + i];
     HIP_TRY(hipMemcpy(c->d_afrag, h.data(), h.size(), hipMemcpyHostToDevice));
+    return MI355_OK;
+}
+
+// Strict mode's first look (jpeg_screen_devfn.h, screen_quantise_f16): the 39-bit fixed-point map as two 11-bit digits
+// Lt39 = D1 2^28 + D0 2^17 + rho, D1 and D0 as integer-valued f16.  Fragment (mt, digit, K half h), lane l = (m = l & 15,
+// g = l >> 4) holds row 16 mt + m, input samples 16 g + 8 h .. + 7 (= row 2 g + h of the 8x8 block: the order in which a
+// lane of the kernel holds its samples).
+uint16_t f16_of_int(int v) {  // |v| <= 2048: exact
+    if (v == 0) return 0;
+    const uint16_t sign = v < 0 ? 0x8000u : 0u;
+    unsigned a = (unsigned)(v < 0 ? -v : v);
+    int e = 0;
+    while ((a >> (e + 1)) != 0) ++e;  // a in [2^e, 2^(e+1))
+    const unsigned mant = (a << (10 - e)) & 0x3FFu;
+    return (uint16_t)(sign | ((unsigned)(e + 15) << 10) | mant);
+}
+constexpr size_t kAfragF16Bytes = (size_t)4 * 4 * 64 * 16;
+int upload_afrag_f16(mi355_jpeg_ctx* c, size_t byte_offset) {
+    std::vector<uint16_t> h(kAfragF16Bytes / 2);
+    for (int mt = 0; mt < 4; ++mt)
+        for (int digit = 0; digit < 2; ++digit)  // fragment order: D1 h0, D1 h1, D0 h0, D0 h1
+            for (int hh = 0; hh < 2; ++hh)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const LookDigits d = split_look(16 * mt + (lane & 15), 16 * (lane >> 4) + 8 * hh + e);
+                        if (d.d1 < -2047 || d.d1 > 2047 || d.d0 < -1024 || d.d0 > 1024) return MI355_E_INTERNAL;
+                        h[((((size_t)mt * 4 + digit * 2 + hh) * 64 + lane) * 8) + e] = f16_of_int(digit == 0 ? d.d1 : d.d0);
+                    }
+    HIP_TRY(hipMemcpy((uint8_t*)c->d_afrag + byte_offset, h.data(), kAfragF16Bytes, hipMemcpyHostToDevice));
     return MI355_OK;
 }
 
@@ -414,11 +488,16 @@ struct ArenaPlan {
     uint32_t grid, region_words;
     size_t total_words;
 };
-ArenaPlan plan_arena(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, size_t need_words) {
+// need_words sizes the waves' private regions (what the frames need if they fit their output); pool_words the shared
+// overflow pool behind them.  The pool is sized for the WORST case of every unit of the part (54 words each), so that
+// it cannot run dry whatever the frames hold: a frame far over its output capacity is then flagged by the capacity
+// check of its own tile scan and by nothing else, and cannot take arena space away from the frames beside it.  (The
+// pool is only touched where a wave's private region has filled up: the pages are reserved, not used.)
+ArenaPlan plan_arena(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, size_t need_words, size_t pool_words) {
     ArenaPlan p;
     p.grid = screen_grid(g, n_frames, c->screen_waves);
     p.region_words = (uint32_t)((need_words + p.grid - 1) / p.grid);
-    p.total_words = (size_t)p.grid * p.region_words + need_words + (size_t)p.grid * 1024 + 64;
+    p.total_words = (size_t)p.grid * p.region_words + pool_words + (size_t)p.grid * 1024 + 64;
     return p;
 }
 
@@ -434,6 +513,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     const bool stdm = (g.flags & MI355_F_STANDARD) != 0;
     sp.afrag = c->d_afrag + (stdm ? kAfragBytes / sizeof(uint4) : 0);
     sp.csc_frag = c->d_afrag + 2 * kAfragBytes / sizeof(uint4);
+    sp.afrag_h = c->d_afrag + (2 * kAfragBytes + (size_t)kCscSets * 1024) / sizeof(uint4);
     sp.qconst = c->d_qconst;
     sp.qconst_f = c->d_qconst_f + (stdm ? 256 : 0);
     sp.qd = c->d_q;
@@ -519,7 +599,7 @@ int run_entropy(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, uint8_t* d_
 
 // One part of a batch: frames [f0, f0 + nf).  Parts alternate between two sets of {meta, arena, overflow counter}:
 // part i + 2 reuses the set of part i once that part's tail kernels are done.
-constexpr uint32_t kCounters = 64;  // overflow counters: part i uses i % 64 (its tile scan re-arms it long before part i + 64)
+constexpr uint32_t kCounters = 64;  // overflow counters: one per workspace set (re-armed by the tile scan of the part that used the set)
 struct BatchPart {
     uint32_t f0, nf;
     ArenaPlan plan;
@@ -579,9 +659,9 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         if (nparts > c->batch_parts) nparts = c->batch_parts;
         if (nparts < 1) nparts = 1;
     }
-    // 32-bit word offsets inside a part: 2 x frame_words x frames + slack must stay below 2^32
+    // 32-bit word offsets inside a part: (frame_words + by_units) x frames + slack must stay below 2^32
     {
-        const uint64_t max_pf = frame_words * 2 + (1u << 16) < (1ull << 32) ? ((1ull << 32) - (1ull << 24)) / (frame_words * 2 + (1u << 16)) : 0;
+        const uint64_t max_pf = frame_words + by_units + (1u << 16) < (1ull << 32) ? ((1ull << 32) - (1ull << 24)) / (frame_words + by_units + (1u << 16)) : 0;
         if (max_pf == 0) return MI355_E_ARG;  // one frame alone beyond 2^32 arena words (> 39 M blocks at the capacity given)
         const uint32_t need_parts = (uint32_t)((n_frames + max_pf - 1) / max_pf);
         if (nparts < need_parts) nparts = need_parts;
@@ -591,7 +671,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         const uint32_t nf = (uint32_t)(((uint64_t)n_frames * (i + 1)) / nparts) - (uint32_t)(((uint64_t)n_frames * i) / nparts);
         max_nf = nf > max_nf ? nf : max_nf;
     }
-    const ArenaPlan big = plan_arena(c, g, max_nf, (size_t)max_nf * frame_words);
+    const ArenaPlan big = plan_arena(c, g, max_nf, (size_t)max_nf * frame_words, (size_t)max_nf * by_units);
     const size_t set_arena = (big.total_words + 63) & ~(size_t)63;
     const size_t set_meta = (size_t)g.tiles * g.passes * 64 * max_nf;
     // Sets of {metadata, arena}: one per part while they fit a budget (a quarter of the free device memory, at most
@@ -609,6 +689,9 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         nsets = (uint32_t)(fit < 2 ? 2 : (fit < nparts ? fit : nparts));
         if (c->max_sets && nsets > c->max_sets) nsets = c->max_sets;  // tests
     }
+    // the overflow counter belongs to the set: the wait that guards a set's reuse then also orders the counter's re-arm
+    // (part i's tile scan) before part i + nsets allocates from it
+    if (nsets > kCounters) nsets = kCounters;
     if (set_arena > 0xFFFFFFFFull) return MI355_E_ARG;  // (cannot happen: parts were sized for it)
     int e;
     if ((e = ensure(c->d_meta, c->meta_cap, set_meta * nsets))) return e;
@@ -629,9 +712,9 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         BatchPart part;
         part.f0 = (uint32_t)(((uint64_t)n_frames * i) / nparts);
         part.nf = (uint32_t)(((uint64_t)n_frames * (i + 1)) / nparts) - part.f0;
-        part.plan = plan_arena(c, g, part.nf, (size_t)part.nf * frame_words);
+        part.plan = plan_arena(c, g, part.nf, (size_t)part.nf * frame_words, (size_t)part.nf * by_units);
         part.set = i % nsets;
-        part.counter = i % kCounters;
+        part.counter = part.set;
         const ScreenParams sp = part_params(c, g, part, set_meta, set_arena);
         if (i >= nsets) HIP_TRY(hipStreamWaitEvent(s, c->ev_set[part.set], 0));  // the tails of part i - nsets are done with this set
         HIP_TRY(launch_screen_encode(g, part.nf, d_rgb + (size_t)part.f0 * g.frame_stride, sp, false, c->screen_waves, s));
@@ -657,7 +740,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
 
 // Screened transform only (stage probes): coefficients into the tiled workspace layout.
 int run_screened_probe(mi355_jpeg_ctx* c, const Geom& g, const uint8_t* d_rgb, uint8_t* d_samples, hipStream_t s) {
-    ArenaPlan plan = plan_arena(c, g, 1, unit_count(g) * 54);
+    ArenaPlan plan = plan_arena(c, g, 1, unit_count(g) * 54, unit_count(g) * 54 + 64);
     if (plan.total_words > 0xFFFFFFFFull) return MI355_E_ARG;
     int e;
     if ((e = ensure_screen_workspace(c, g, 1, plan.total_words))) return e;
@@ -729,6 +812,21 @@ int status_to_error(uint32_t st) {
     return MI355_OK;
 }
 
+// No exception crosses the C ABI (SURVEY §8 b; the reference's counterpart is -1 + a message, utils.cpp:17-63): every
+// entry point that can allocate on the host (std::vector, std::thread, push_back) runs inside this barrier.
+template <typename F>
+int guarded(F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return MI355_E_ALLOC;
+    } catch (const std::system_error&) {  // a worker thread could not be started
+        return MI355_E_ALLOC;
+    } catch (...) {
+        return MI355_E_INTERNAL;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -757,7 +855,7 @@ int mi355_jpeg_device_count(void) {
     return n;
 }
 
-int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
+static int create_body(int device_id, mi355_jpeg_ctx** out){
     if (!out) return MI355_E_ARG;
     *out = nullptr;
     Knobs kn;
@@ -787,18 +885,19 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
         hipMalloc((void**)&c->d_qzz, 128 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut, 2048 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_status, sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_afrag, 2 * kAfragBytes + (size_t)kCscSets * 1024) != hipSuccess ||
+        hipMalloc((void**)&c->d_afrag, 2 * kAfragBytes + (size_t)kCscSets * 1024 + kAfragF16Bytes) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst_f, 512 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut2, 4 * 66 * 16 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_counters, 64 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_stats, 2 * sizeof(unsigned long long)) != hipSuccess)
+        hipMalloc((void**)&c->d_stats, 4 * sizeof(unsigned long long)) != hipSuccess)
         e = MI355_E_ALLOC;
-    if (!e) e = hip_err(hipMemset(c->d_stats, 0, 2 * sizeof(unsigned long long)));
+    if (!e) e = hip_err(hipMemset(c->d_stats, 0, 4 * sizeof(unsigned long long)));
     if (!e) e = hip_err(hipMemset(c->d_status, 0, sizeof(uint32_t)));
     if (!e) e = hip_err(hipMemset(c->d_counters, 0, 64 * sizeof(uint32_t)));
     if (!e) e = upload_afrag(c);
     if (!e) e = upload_csc_frag(c);
+    if (!e) e = upload_afrag_f16(c, 2 * kAfragBytes + (size_t)kCscSets * 1024);
     if (!e) e = upload_tables(c);
     if (!e) e = hip_err(hipDeviceSynchronize());  // every fill and table copy above has landed
     if (e) {
@@ -807,6 +906,9 @@ int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
     }
     *out = c;
     return MI355_OK;
+}
+int mi355_jpeg_create(int device_id, mi355_jpeg_ctx** out) {
+    return guarded([&]() -> int { return create_body(device_id, out); });
 }
 
 void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
@@ -831,7 +933,7 @@ void mi355_jpeg_destroy(mi355_jpeg_ctx* c) {
     delete c;
 }
 
-int mi355_jpeg_set_quant(mi355_jpeg_ctx* c, const uint32_t qlum[64], const uint32_t qchrom[64]) {
+static int set_quant_body(mi355_jpeg_ctx* c, const uint32_t qlum[64], const uint32_t qchrom[64]){
     if (!c || !qlum || !qchrom) return MI355_E_ARG;
     for (int i = 0; i < 64; ++i)
         if (qlum[i] < 1 || qlum[i] > 65535 || qchrom[i] < 1 || qchrom[i] > 65535) return MI355_E_TABLE;
@@ -840,8 +942,11 @@ int mi355_jpeg_set_quant(mi355_jpeg_ctx* c, const uint32_t qlum[64], const uint3
     HIP_TRY(hipSetDevice(c->device));
     return upload_tables(c);
 }
+int mi355_jpeg_set_quant(mi355_jpeg_ctx* c, const uint32_t qlum[64], const uint32_t qchrom[64]) {
+    return guarded([&]() -> int { return set_quant_body(c, qlum, qchrom); });
+}
 
-int mi355_jpeg_set_quality(mi355_jpeg_ctx* c, int quality) {
+static int set_quality_body(mi355_jpeg_ctx* c, int quality){
     if (!c || quality < 1 || quality > 100) return MI355_E_ARG;
     uint32_t ql[64], qc[64];
     int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
@@ -852,8 +957,11 @@ int mi355_jpeg_set_quality(mi355_jpeg_ctx* c, int quality) {
     }
     return mi355_jpeg_set_quant(c, ql, qc);
 }
+int mi355_jpeg_set_quality(mi355_jpeg_ctx* c, int quality) {
+    return guarded([&]() -> int { return set_quality_body(c, quality); });
+}
 
-int mi355_jpeg_set_huffman(mi355_jpeg_ctx* c, int table, const mi355_huff_table* t) {
+static int set_huffman_body(mi355_jpeg_ctx* c, int table, const mi355_huff_table* t){
     if (!c || table < 0 || table > 3) return MI355_E_ARG;
     mi355_huff_table nt;
     if (t) {
@@ -872,30 +980,45 @@ int mi355_jpeg_set_huffman(mi355_jpeg_ctx* c, int table, const mi355_huff_table*
     HIP_TRY(hipSetDevice(c->device));
     return upload_tables(c);
 }
+int mi355_jpeg_set_huffman(mi355_jpeg_ctx* c, int table, const mi355_huff_table* t) {
+    return guarded([&]() -> int { return set_huffman_body(c, table, t); });
+}
 
-int mi355_jpeg_set_encode_waves(mi355_jpeg_ctx* c, uint32_t waves) {
+static int set_encode_waves_body(mi355_jpeg_ctx* c, uint32_t waves){
     if (!c || (waves != 0 && (waves < 32 || waves > 8192 || (waves & 31)))) return MI355_E_ARG;
     c->screen_waves = waves ? waves : (c->n_cus > 0 ? 8u * (uint32_t)c->n_cus : 2048u);
     return MI355_OK;
 }
+int mi355_jpeg_set_encode_waves(mi355_jpeg_ctx* c, uint32_t waves) {
+    return guarded([&]() -> int { return set_encode_waves_body(c, waves); });
+}
 
-int mi355_jpeg_reference_huffman(int table, mi355_huff_table* t) {
+static int reference_huffman_body(int table, mi355_huff_table* t){
     if (!t || table < 0 || table > 3) return MI355_E_ARG;
     reference_huffman(table, t);
     return MI355_OK;
 }
+int mi355_jpeg_reference_huffman(int table, mi355_huff_table* t) {
+    return guarded([&]() -> int { return reference_huffman_body(table, t); });
+}
 
-int mi355_jpeg_get_quant(mi355_jpeg_ctx* c, uint32_t qlum[64], uint32_t qchrom[64]) {
+static int get_quant_body(mi355_jpeg_ctx* c, uint32_t qlum[64], uint32_t qchrom[64]){
     if (!c || !qlum || !qchrom) return MI355_E_ARG;
     memcpy(qlum, c->qlum, sizeof c->qlum);
     memcpy(qchrom, c->qchrom, sizeof c->qchrom);
     return MI355_OK;
 }
+int mi355_jpeg_get_quant(mi355_jpeg_ctx* c, uint32_t qlum[64], uint32_t qchrom[64]) {
+    return guarded([&]() -> int { return get_quant_body(c, qlum, qchrom); });
+}
 
-int mi355_jpeg_get_huffman(mi355_jpeg_ctx* c, int table, mi355_huff_table* t) {
+static int get_huffman_body(mi355_jpeg_ctx* c, int table, mi355_huff_table* t){
     if (!c || !t || table < 0 || table > 3) return MI355_E_ARG;
     *t = c->huff[table];
     return MI355_OK;
+}
+int mi355_jpeg_get_huffman(mi355_jpeg_ctx* c, int table, mi355_huff_table* t) {
+    return guarded([&]() -> int { return get_huffman_body(c, table, t); });
 }
 
 void mi355_jpeg_padded_size(uint32_t W, uint32_t H, uint32_t* W8, uint32_t* H8) {
@@ -916,9 +1039,9 @@ size_t mi355_jpeg_scan_bound_flags(uint32_t W, uint32_t H, uint32_t flags) {
     return (bits + 7) / 8 + 8;
 }
 
-int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t W, uint32_t H,
+static int encode_scan_device_body(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t W, uint32_t H,
                                   uint32_t n_frames, uint32_t flags, void* d_out, size_t out_stride,
-                                  uint64_t* d_bits, void* stream) {
+                                  uint64_t* d_bits, void* stream){
     if (!c || !d_rgb || !d_out || !d_bits || n_frames == 0 || out_stride < 8 || (out_stride & 3) ||
         ((uintptr_t)d_out & 3))
         return MI355_E_ARG;
@@ -943,8 +1066,13 @@ int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t
     record(c, 1, s);
     return run_entropy(c, g, n_frames, (uint8_t*)d_out, out_stride, d_bits, s);
 }
+int mi355_jpeg_encode_scan_device(mi355_jpeg_ctx* c, const void* d_rgb, uint32_t W, uint32_t H,
+                                  uint32_t n_frames, uint32_t flags, void* d_out, size_t out_stride,
+                                  uint64_t* d_bits, void* stream) {
+    return guarded([&]() -> int { return encode_scan_device_body(c, d_rgb, W, H, n_frames, flags, d_out, out_stride, d_bits, stream); });
+}
 
-int mi355_jpeg_sync(mi355_jpeg_ctx* c, void* stream) {
+static int sync_body(mi355_jpeg_ctx* c, void* stream){
     if (!c) return MI355_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -1012,10 +1140,13 @@ int mi355_jpeg_sync(mi355_jpeg_ctx* c, void* stream) {
     }
     return status_to_error(st);
 }
+int mi355_jpeg_sync(mi355_jpeg_ctx* c, void* stream) {
+    return guarded([&]() -> int { return sync_body(c, stream); });
+}
 
-int mi355_jpeg_encode_scan(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H,
+static int encode_scan_body(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H,
                            uint32_t n_frames, uint32_t flags, uint8_t* out, size_t out_stride,
-                           uint64_t* bits) {
+                           uint64_t* bits){
     if (!c || !rgb || !out || !bits || n_frames == 0) return MI355_E_ARG;
     Geom g;
     int e = make_geom(W, H, flags, nullptr, &g);
@@ -1040,11 +1171,16 @@ int mi355_jpeg_encode_scan(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, ui
     }
     return MI355_OK;
 }
+int mi355_jpeg_encode_scan(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H,
+                           uint32_t n_frames, uint32_t flags, uint8_t* out, size_t out_stride,
+                           uint64_t* bits) {
+    return guarded([&]() -> int { return encode_scan_body(c, rgb, W, H, n_frames, flags, out, out_stride, bits); });
+}
 
 // ---- stage probes -----------------------------------------------------------
 
-int mi355_jpeg_probe_samples(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
-                             uint8_t* out) {
+static int probe_samples_body(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
+                             uint8_t* out){
     if (!c || !rgb || !out) return MI355_E_ARG;
     Geom g;
     int e = make_geom(W, H, flags, nullptr, &g);
@@ -1066,6 +1202,10 @@ int mi355_jpeg_probe_samples(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, 
     HIP_TRY(hipMemcpy(out, c->d_out, ob, hipMemcpyDeviceToHost));
     return MI355_OK;
 }
+int mi355_jpeg_probe_samples(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
+                             uint8_t* out) {
+    return guarded([&]() -> int { return probe_samples_body(c, rgb, W, H, flags, out); });
+}
 
 static int transform_to_workspace(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H,
                                   uint32_t flags, Geom* g) {
@@ -1081,8 +1221,8 @@ static int transform_to_workspace(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_
     return MI355_OK;
 }
 
-int mi355_jpeg_probe_coefficients(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H,
-                                  uint32_t flags, int16_t* out) {
+static int probe_coefficients_body(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H,
+                                  uint32_t flags, int16_t* out){
     if (!c || !rgb || !out) return MI355_E_ARG;
     Geom g;
     int e = transform_to_workspace(c, rgb, W, H, flags, &g);
@@ -1093,9 +1233,13 @@ int mi355_jpeg_probe_coefficients(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_
     HIP_TRY(hipMemcpy(out, c->d_out, ob, hipMemcpyDeviceToHost));
     return MI355_OK;
 }
+int mi355_jpeg_probe_coefficients(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H,
+                                  uint32_t flags, int16_t* out) {
+    return guarded([&]() -> int { return probe_coefficients_body(c, rgb, W, H, flags, out); });
+}
 
-int mi355_jpeg_probe_unit_bits(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
-                               uint32_t* out) {
+static int probe_unit_bits_body(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
+                               uint32_t* out){
     if (!c || !rgb || !out) return MI355_E_ARG;
     if (flags & MI355_F_STANDARD) return MI355_E_ARG;  // the per-unit size kernel codes the reference's rules only
     Geom g;
@@ -1110,9 +1254,13 @@ int mi355_jpeg_probe_unit_bits(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W
     HIP_TRY(hipMemcpy(out, c->d_out, ob, hipMemcpyDeviceToHost));
     return MI355_OK;
 }
+int mi355_jpeg_probe_unit_bits(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
+                               uint32_t* out) {
+    return guarded([&]() -> int { return probe_unit_bits_body(c, rgb, W, H, flags, out); });
+}
 
-int mi355_jpeg_entropy_only(mi355_jpeg_ctx* c, const int16_t* zigzag, uint32_t n_blocks, uint8_t* out,
-                            size_t cap, uint64_t* bits) {
+static int entropy_only_body(mi355_jpeg_ctx* c, const int16_t* zigzag, uint32_t n_blocks, uint8_t* out,
+                            size_t cap, uint64_t* bits){
     if (!c || !zigzag || !out || !bits || n_blocks == 0) return MI355_E_ARG;
     Geom g;
     memset(&g, 0, sizeof g);
@@ -1137,6 +1285,10 @@ int mi355_jpeg_entropy_only(mi355_jpeg_ctx* c, const int16_t* zigzag, uint32_t n
     if (nb > cap) return MI355_E_CAPACITY;
     HIP_TRY(hipMemcpy(out, c->d_out, nb, hipMemcpyDeviceToHost));
     return MI355_OK;
+}
+int mi355_jpeg_entropy_only(mi355_jpeg_ctx* c, const int16_t* zigzag, uint32_t n_blocks, uint8_t* out,
+                            size_t cap, uint64_t* bits) {
+    return guarded([&]() -> int { return entropy_only_body(c, zigzag, n_blocks, out, cap, bits); });
 }
 
 // ---- JFIF framing (build-defined) ----------------------
@@ -1220,8 +1372,8 @@ size_t jfif_header(const mi355_jpeg_ctx* c, uint32_t W, uint32_t H, uint32_t fla
 }
 }  // namespace
 
-int mi355_jpeg_wrap_jfif(mi355_jpeg_ctx* c, const uint8_t* scan, uint64_t n_bits, uint32_t W, uint32_t H, uint32_t flags,
-                         uint8_t* out, size_t cap, size_t* out_len) {
+static int wrap_jfif_body(mi355_jpeg_ctx* c, const uint8_t* scan, uint64_t n_bits, uint32_t W, uint32_t H, uint32_t flags,
+                         uint8_t* out, size_t cap, size_t* out_len){
     if (!c || !scan || !out || !out_len || W == 0 || H == 0 || W > 65535u || H > 65535u) return MI355_E_ARG;
     if ((flags & MI355_F_420) && !(flags & MI355_F_STANDARD)) return MI355_E_ARG;
     if (flags & MI355_F_RESTART) return MI355_E_ARG;  // the markers go in with the stuffing, on the device
@@ -1238,9 +1390,13 @@ int mi355_jpeg_wrap_jfif(mi355_jpeg_ctx* c, const uint8_t* scan, uint64_t n_bits
     *out_len = w.n;
     return w.n > cap ? MI355_E_CAPACITY : MI355_OK;
 }
+int mi355_jpeg_wrap_jfif(mi355_jpeg_ctx* c, const uint8_t* scan, uint64_t n_bits, uint32_t W, uint32_t H, uint32_t flags,
+                         uint8_t* out, size_t cap, size_t* out_len) {
+    return guarded([&]() -> int { return wrap_jfif_body(c, scan, n_bits, W, H, flags, out, cap, out_len); });
+}
 
-int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
-                           uint8_t* out, size_t cap, size_t* out_len) {
+static int encode_jfif_body(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
+                           uint8_t* out, size_t cap, size_t* out_len){
     if (!c || !rgb || !out || !out_len) return MI355_E_ARG;
     Geom g;
     int e = make_geom(W, H, flags, nullptr, &g);
@@ -1283,20 +1439,32 @@ int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, ui
     }
     return MI355_E_CAPACITY;
 }
+int mi355_jpeg_encode_jfif(mi355_jpeg_ctx* c, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t flags,
+                           uint8_t* out, size_t cap, size_t* out_len) {
+    return guarded([&]() -> int { return encode_jfif_body(c, rgb, W, H, flags, out, cap, out_len); });
+}
 
 // ---- either side of the path ------------------------------------------------------------
 
-int mi355_jpeg_synth_lcg_device(mi355_jpeg_ctx* c, void* d_dst, size_t frame_bytes, uint32_t n_frames, uint32_t seed0,
-                                void* stream) {
+static int synth_lcg_device_body(mi355_jpeg_ctx* c, void* d_dst, size_t frame_bytes, uint32_t n_frames, uint32_t seed0,
+                                void* stream){
     if (!c || !d_dst || frame_bytes == 0 || n_frames == 0 || n_frames > 65535u) return MI355_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_lcg_fill((uint8_t*)d_dst, frame_bytes, n_frames, seed0, (hipStream_t)stream));
     return MI355_OK;
 }
+int mi355_jpeg_synth_lcg_device(mi355_jpeg_ctx* c, void* d_dst, size_t frame_bytes, uint32_t n_frames, uint32_t seed0,
+                                void* stream) {
+    return guarded([&]() -> int { return synth_lcg_device_body(c, d_dst, frame_bytes, n_frames, seed0, stream); });
+}
 
+static int stuff_device_body(mi355_jpeg_ctx* c, const void* d_scan, const uint64_t* d_bits, size_t max_scan_bytes,
+                            void* d_out, size_t cap, uint64_t* d_out_len, void* stream){
+    return stuff_scan(c, d_scan, d_bits, max_scan_bytes, d_out, cap, d_out_len, nullptr, 0, stream);
+}
 int mi355_jpeg_stuff_device(mi355_jpeg_ctx* c, const void* d_scan, const uint64_t* d_bits, size_t max_scan_bytes,
                             void* d_out, size_t cap, uint64_t* d_out_len, void* stream) {
-    return stuff_scan(c, d_scan, d_bits, max_scan_bytes, d_out, cap, d_out_len, nullptr, 0, stream);
+    return guarded([&]() -> int { return stuff_device_body(c, d_scan, d_bits, max_scan_bytes, d_out, cap, d_out_len, stream); });
 }
 
 }  // extern "C"
@@ -1343,7 +1511,8 @@ namespace {
 
 struct PoolJob {
     const uint8_t* rgb = nullptr;
-    uint32_t W = 0, H = 0, lo = 0, hi = 0, flags = 0;
+    uint32_t W = 0, H = 0, n = 0, chunk = 1, flags = 0;
+    std::atomic<uint32_t>* cursor = nullptr;  // next frame nobody has taken yet (shared by the workers of one call)
     uint8_t* out = nullptr;
     size_t out_stride = 0;
     uint64_t* bits = nullptr;
@@ -1436,7 +1605,6 @@ bool pool_ensure(mi355_jpeg_pool* p, T*& ptr, size_t& cap, size_t need) {
 
 void pool_run(PoolWorker* w, PoolJob* j) {
     j->rc = MI355_OK;
-    if (j->lo >= j->hi) return;
     mi355_jpeg_ctx* c = w->c;
     mi355_jpeg_pool* pool = w->pool;
     if (hipSetDevice(c->device) != hipSuccess) {
@@ -1446,10 +1614,9 @@ void pool_run(PoolWorker* w, PoolJob* j) {
     const size_t fbytes = (size_t)j->W * j->H * 3;
     size_t dstride = (j->out_stride + 3) & ~(size_t)3;
     if (dstride < 8) dstride = 8;
-    // chunk: about 256 MB of input, at least 1 frame
-    uint32_t chunk = (uint32_t)((256u << 20) / fbytes);
-    if (chunk < 1) chunk = 1;
-    if (chunk > j->hi - j->lo) chunk = j->hi - j->lo;
+    // Work is handed out in chunks from a cursor all workers of the call share (about 256 MB of input each, less for
+    // small batches so that every worker gets some): a GPU that is slower today simply takes fewer chunks.
+    const uint32_t chunk = j->chunk;
     int rc = MI355_OK;
     auto H = [&](hipError_t e) {
         if (e != hipSuccess && rc == MI355_OK) rc = MI355_E_HIP - (int)e;
@@ -1485,42 +1652,43 @@ void pool_run(PoolWorker* w, PoolJob* j) {
     // (caller memory that is not registered through the pool was registered for this call by pool_encode, as ONE range
     // per buffer: slabs registered worker by worker share pages at their ends, and a page unpinned by the worker that
     // finishes first is a page the other worker's DMA still targets)
-    const uint32_t nchunks = (j->hi - j->lo + chunk - 1) / chunk;
-    auto frames_of = [&](uint32_t k) { uint32_t a = j->lo + k * chunk; return (a + chunk <= j->hi ? chunk : j->hi - a); };
+    uint32_t first_of[2] = {0, 0}, frames_of[2] = {0, 0};  // the chunk in flight in each of the two buffer sets
     int frame_rc = MI355_OK;  // a frame that does not fit / has no code: the others still come back
-    auto drain = [&](uint32_t k) {  // chunk k is encoded: fetch its bit counts, then its bytes
-        const int b = (int)(k & 1);
-        const uint32_t a = j->lo + k * chunk, nf = frames_of(k);
+    auto drain = [&](int b) {  // the chunk in buffer set b is encoded: fetch its bit counts, then its bytes
+        const uint32_t a = first_of[b], nf = frames_of[b];
         H(hipStreamWaitEvent(s_out, ev_cmp[b], 0));
         H(hipMemcpyAsync(h_bits + (size_t)b * chunk, d_bits[b], sizeof(uint64_t) * nf, hipMemcpyDeviceToHost, s_out));
         H(hipStreamSynchronize(s_out));
         for (uint32_t f = 0; f < nf && rc == MI355_OK; ++f) {
             const uint64_t nb = h_bits[(size_t)b * chunk + f];
-            j->bits[a + f] = nb;
-            if (nb == ~0ull) {  // flagged by the device (capacity or category: mi355_jpeg_sync below says which came first)
-                if (j->frame_status) j->frame_status[a + f] = MI355_E_CAPACITY;
-                if (frame_rc == MI355_OK) frame_rc = MI355_E_CAPACITY;
+            int st = MI355_OK;
+            if (nb >= kBitsFlagged) {  // the device's verdict for this frame, with its cause
+                st = nb == kBitsCategory ? MI355_E_CATEGORY : MI355_E_CAPACITY;
+            } else if ((size_t)((nb + 7) / 8) > j->out_stride) {  // fits the 4-byte-rounded device slot, not the caller's
+                st = MI355_E_CAPACITY;
+            }
+            j->bits[a + f] = st == MI355_OK ? nb : (st == MI355_E_CATEGORY ? kBitsCategory : kBitsCapacity);
+            if (j->frame_status) j->frame_status[a + f] = st;
+            if (st != MI355_OK) {
+                if (frame_rc == MI355_OK || st == MI355_E_CATEGORY) frame_rc = st;  // (category first, like mi355_jpeg_sync)
                 continue;
             }
-            const size_t bytes = (size_t)((nb + 7) / 8);
-            if (bytes > j->out_stride) {  // fits the 4-byte-rounded device slot, not the caller's
-                if (j->frame_status) j->frame_status[a + f] = MI355_E_CAPACITY;
-                if (frame_rc == MI355_OK) frame_rc = MI355_E_CAPACITY;
-                continue;
-            }
-            if (j->frame_status) j->frame_status[a + f] = MI355_OK;
-            H(hipMemcpyAsync(j->out + (size_t)(a + f) * j->out_stride, d_out[b] + (size_t)f * dstride, bytes,
+            H(hipMemcpyAsync(j->out + (size_t)(a + f) * j->out_stride, d_out[b] + (size_t)f * dstride, (size_t)((nb + 7) / 8),
                              hipMemcpyDeviceToHost, s_out));
         }
         H(hipEventRecord(ev_out[b], s_out));
     };
-    for (uint32_t k = 0; k < nchunks && rc == MI355_OK; ++k) {
+    uint32_t k = 0;
+    for (; rc == MI355_OK; ++k) {
+        const uint32_t a = j->cursor->fetch_add(chunk);
+        if (a >= j->n) break;
         const int b = (int)(k & 1);
-        const uint32_t a = j->lo + k * chunk, nf = frames_of(k);
+        const uint32_t nf = a + chunk <= j->n ? chunk : j->n - a;
         if (k >= 2) {  // buffers of chunk k-2 must be fully drained before reuse
             H(hipStreamWaitEvent(s_in, ev_out[b], 0));
             H(hipStreamWaitEvent(s_cmp, ev_out[b], 0));
         }
+        first_of[b] = a, frames_of[b] = nf;
         H(hipMemcpyAsync(d_in[b], j->rgb + (size_t)a * fbytes, fbytes * nf, hipMemcpyHostToDevice, s_in));
         H(hipEventRecord(ev_in[b], s_in));
         H(hipStreamWaitEvent(s_cmp, ev_in[b], 0));
@@ -1529,19 +1697,16 @@ void pool_run(PoolWorker* w, PoolJob* j) {
             if (e) rc = e;
         }
         H(hipEventRecord(ev_cmp[b], s_cmp));
-        if (k >= 1 && rc == MI355_OK) drain(k - 1);  // overlaps the encode of chunk k
+        if (k >= 1 && rc == MI355_OK) drain((int)((k - 1) & 1));  // overlaps the encode of chunk k
     }
-    if (rc == MI355_OK) drain(nchunks - 1);
+    if (k >= 1 && rc == MI355_OK) drain((int)((k - 1) & 1));
     if (s_out) (void)hipStreamSynchronize(s_out);
     if (s_in) (void)hipStreamSynchronize(s_in);
     if (s_cmp) {
-        const int e = mi355_jpeg_sync(c, s_cmp);  // also clears the device-side status for the next call
-        if (rc == MI355_OK && e) {
-            rc = e;
-            if (j->frame_status && (e == MI355_E_CATEGORY || e == MI355_E_CAPACITY))
-                for (uint32_t f = j->lo; f < j->hi; ++f)
-                    if (j->bits[f] == ~0ull) j->frame_status[f] = e;  // the shard's first device-side error
-        }
+        // also clears the device-side status for the next call.  Capacity / category are reported per frame above; what
+        // is left for the call's return value is anything else (a HIP error, MI355_E_INTERNAL).
+        const int e = mi355_jpeg_sync(c, s_cmp);
+        if (rc == MI355_OK && e && e != MI355_E_CATEGORY && e != MI355_E_CAPACITY) rc = e;
     }
     if (rc == MI355_OK) rc = frame_rc;
     j->rc = rc;
@@ -1575,18 +1740,16 @@ bool pool_covers(mi355_jpeg_pool* p, const void* ptr, size_t bytes) {
 
 extern "C" {
 
-int mi355_jpeg_pool_create(const int* device_ids, int n_workers, mi355_jpeg_pool** out) {
+static int pool_create_body(const int* device_ids, int n_workers, mi355_jpeg_pool** out){
     if (!out) return MI355_E_ARG;
     *out = nullptr;
+    if (device_ids && n_workers <= 0) return MI355_E_ARG;
+    std::vector<int> ids;
+    if (device_ids) ids.assign(device_ids, device_ids + n_workers);  // (may throw std::bad_alloc: stopped at the boundary)
     int ndev = mi355_jpeg_device_count();
     if (ndev <= 0) return MI355_E_NO_DEVICE;
-    std::vector<int> ids;
-    if (device_ids) {
-        if (n_workers <= 0) return MI355_E_ARG;
-        ids.assign(device_ids, device_ids + n_workers);
-    } else {
+    if (!device_ids)
         for (int d = 0; d < ndev; ++d) ids.push_back(d);
-    }
     mi355_jpeg_pool* p = new (std::nothrow) mi355_jpeg_pool();
     if (!p) return MI355_E_ALLOC;
     for (int id : ids) {
@@ -1605,11 +1768,29 @@ int mi355_jpeg_pool_create(const int* device_ids, int n_workers, mi355_jpeg_pool
         w->pool = p;
         w->c = c;
         w->numa_node = gpu_numa_node(id);
-        p->w.push_back(w);
-        w->th = std::thread(pool_thread, w);
+        // Whatever throws from here on (the worker list growing, a thread that cannot start: std::system_error with
+        // EAGAIN under a process limit), the pool made so far is torn down -- threads joined, contexts destroyed -- and
+        // the caller gets MI355_E_ALLOC.
+        try {
+            p->w.push_back(w);
+        } catch (...) {
+            mi355_jpeg_destroy(c);
+            delete w;
+            mi355_jpeg_pool_destroy(p);
+            return MI355_E_ALLOC;
+        }
+        try {
+            w->th = std::thread(pool_thread, w);
+        } catch (...) {
+            mi355_jpeg_pool_destroy(p);
+            return MI355_E_ALLOC;
+        }
     }
     *out = p;
     return MI355_OK;
+}
+int mi355_jpeg_pool_create(const int* device_ids, int n_workers, mi355_jpeg_pool** out) {
+    return guarded([&]() -> int { return pool_create_body(device_ids, n_workers, out); });
 }
 
 void mi355_jpeg_pool_destroy(mi355_jpeg_pool* p) {
@@ -1643,7 +1824,7 @@ void mi355_jpeg_pool_destroy(mi355_jpeg_pool* p) {
 
 int mi355_jpeg_pool_workers(mi355_jpeg_pool* p) { return p ? (int)p->w.size() : 0; }
 
-int mi355_jpeg_pool_set_quant(mi355_jpeg_pool* p, const uint32_t qlum[64], const uint32_t qchrom[64]) {
+static int pool_set_quant_body(mi355_jpeg_pool* p, const uint32_t qlum[64], const uint32_t qchrom[64]){
     if (!p) return MI355_E_ARG;
     for (auto* w : p->w) {
         int e = mi355_jpeg_set_quant(w->c, qlum, qchrom);
@@ -1651,8 +1832,11 @@ int mi355_jpeg_pool_set_quant(mi355_jpeg_pool* p, const uint32_t qlum[64], const
     }
     return MI355_OK;
 }
+int mi355_jpeg_pool_set_quant(mi355_jpeg_pool* p, const uint32_t qlum[64], const uint32_t qchrom[64]) {
+    return guarded([&]() -> int { return pool_set_quant_body(p, qlum, qchrom); });
+}
 
-int mi355_jpeg_pool_set_quality(mi355_jpeg_pool* p, int quality) {
+static int pool_set_quality_body(mi355_jpeg_pool* p, int quality){
     if (!p) return MI355_E_ARG;
     for (auto* w : p->w) {
         int e = mi355_jpeg_set_quality(w->c, quality);
@@ -1660,8 +1844,23 @@ int mi355_jpeg_pool_set_quality(mi355_jpeg_pool* p, int quality) {
     }
     return MI355_OK;
 }
+int mi355_jpeg_pool_set_quality(mi355_jpeg_pool* p, int quality) {
+    return guarded([&]() -> int { return pool_set_quality_body(p, quality); });
+}
 
-int mi355_jpeg_pool_register(mi355_jpeg_pool* p, void* ptr, size_t bytes) {
+static int pool_set_huffman_body(mi355_jpeg_pool* p, int table, const mi355_huff_table* t) {
+    if (!p) return MI355_E_ARG;
+    for (auto* w : p->w) {
+        int e = mi355_jpeg_set_huffman(w->c, table, t);
+        if (e) return e;
+    }
+    return MI355_OK;
+}
+int mi355_jpeg_pool_set_huffman(mi355_jpeg_pool* p, int table, const mi355_huff_table* t) {
+    return guarded([&]() -> int { return pool_set_huffman_body(p, table, t); });
+}
+
+static int pool_register_body(mi355_jpeg_pool* p, void* ptr, size_t bytes){
     if (!p || !ptr || !bytes) return MI355_E_ARG;
     if (pool_covers(p, ptr, bytes)) return MI355_OK;
     if (!p->w.empty()) HIP_TRY(hipSetDevice(p->w[0]->c->device));
@@ -1671,8 +1870,11 @@ int mi355_jpeg_pool_register(mi355_jpeg_pool* p, void* ptr, size_t bytes) {
     p->registered.push_back({(uintptr_t)ptr, bytes});
     return MI355_OK;
 }
+int mi355_jpeg_pool_register(mi355_jpeg_pool* p, void* ptr, size_t bytes) {
+    return guarded([&]() -> int { return pool_register_body(p, ptr, bytes); });
+}
 
-int mi355_jpeg_pool_unregister(mi355_jpeg_pool* p, void* ptr) {
+static int pool_unregister_body(mi355_jpeg_pool* p, void* ptr){
     if (!p || !ptr) return MI355_E_ARG;
     std::lock_guard<std::mutex> g(p->reg_mu);
     for (size_t i = 0; i < p->registered.size(); ++i)
@@ -1683,16 +1885,22 @@ int mi355_jpeg_pool_unregister(mi355_jpeg_pool* p, void* ptr) {
         }
     return MI355_E_ARG;
 }
+int mi355_jpeg_pool_unregister(mi355_jpeg_pool* p, void* ptr) {
+    return guarded([&]() -> int { return pool_unregister_body(p, ptr); });
+}
 
-int mi355_jpeg_pool_debug_counts(mi355_jpeg_pool* p, uint64_t counts[4]) {
+static int pool_debug_counts_body(mi355_jpeg_pool* p, uint64_t counts[4]){
     if (!p || !counts) return MI355_E_ARG;
     counts[0] = p->n_alloc, counts[1] = p->n_register, counts[2] = p->n_objects, counts[3] = p->n_calls;
     return MI355_OK;
 }
+int mi355_jpeg_pool_debug_counts(mi355_jpeg_pool* p, uint64_t counts[4]) {
+    return guarded([&]() -> int { return pool_debug_counts_body(p, counts); });
+}
 
-int mi355_jpeg_pool_encode_ex(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t n_frames,
+static int pool_encode_ex_body(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t n_frames,
                               uint32_t flags, uint8_t* out, size_t out_stride, uint64_t* bits, int* frame_status,
-                              double* seconds) {
+                              double* seconds){
     if (!p || p->w.empty() || !rgb || !out || !bits || n_frames == 0) return MI355_E_ARG;
     Geom g;
     int e = make_geom(W, H, flags, nullptr, &g);
@@ -1716,12 +1924,23 @@ int mi355_jpeg_pool_encode_ex(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W
         if (tmp_out) p->n_register++;
     }
     (void)hipGetLastError();
+    // Every frame starts as "not delivered": whatever ends a worker early (a HIP error, an allocation that fails), the
+    // caller finds a defined verdict in bits[] / frame_status[] for the frames that worker never reached.
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        bits[f] = kBitsCapacity;
+        if (frame_status) frame_status[f] = MI355_E_NOT_ENCODED;
+    }
+    std::atomic<uint32_t> cursor{0};
+    uint32_t chunk = (uint32_t)((256u << 20) / ((size_t)g.frame_stride ? (size_t)g.frame_stride : 1));
+    const uint32_t share = (n_frames + nw * 4 - 1) / (nw * 4);  // small batches: at least four chunks per worker
+    if (chunk > share) chunk = share;
+    if (chunk < 1) chunk = 1;
     std::vector<PoolJob> jobs(nw);
     for (uint32_t w = 0; w < nw; ++w) {
         PoolJob& jb = jobs[w];
         jb.rgb = rgb, jb.W = W, jb.H = H, jb.flags = flags, jb.out = out, jb.out_stride = out_stride, jb.bits = bits;
         jb.frame_status = frame_status;
-        jb.lo = (uint32_t)((uint64_t)n_frames * w / nw), jb.hi = (uint32_t)((uint64_t)n_frames * (w + 1) / nw);
+        jb.n = n_frames, jb.chunk = chunk, jb.cursor = &cursor;
         PoolWorker* pw = p->w[w];
         {
             std::lock_guard<std::mutex> gk(pw->mu);
@@ -1737,14 +1956,28 @@ int mi355_jpeg_pool_encode_ex(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W
     if (tmp_in) (void)hipHostUnregister((void*)rgb);
     if (tmp_out) (void)hipHostUnregister((void*)out);
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for (auto& jb : jobs)
-        if (jb.rc) return jb.rc;
-    return MI355_OK;
+    int rc = MI355_OK;  // hard errors first, then category, then capacity
+    for (auto& jb : jobs) {
+        const int e = jb.rc;
+        if (!e) continue;
+        const bool soft_e = e == MI355_E_CATEGORY || e == MI355_E_CAPACITY, soft_rc = rc == MI355_E_CATEGORY || rc == MI355_E_CAPACITY;
+        if (rc == MI355_OK || (soft_rc && !soft_e) || (rc == MI355_E_CAPACITY && e == MI355_E_CATEGORY)) rc = e;
+    }
+    return rc;
+}
+int mi355_jpeg_pool_encode_ex(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t n_frames,
+                              uint32_t flags, uint8_t* out, size_t out_stride, uint64_t* bits, int* frame_status,
+                              double* seconds) {
+    return guarded([&]() -> int { return pool_encode_ex_body(p, rgb, W, H, n_frames, flags, out, out_stride, bits, frame_status, seconds); });
 }
 
+static int pool_encode_body(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t n_frames,
+                           uint32_t flags, uint8_t* out, size_t out_stride, uint64_t* bits, double* seconds){
+    return mi355_jpeg_pool_encode_ex(p, rgb, W, H, n_frames, flags, out, out_stride, bits, nullptr, seconds);
+}
 int mi355_jpeg_pool_encode(mi355_jpeg_pool* p, const uint8_t* rgb, uint32_t W, uint32_t H, uint32_t n_frames,
                            uint32_t flags, uint8_t* out, size_t out_stride, uint64_t* bits, double* seconds) {
-    return mi355_jpeg_pool_encode_ex(p, rgb, W, H, n_frames, flags, out, out_stride, bits, nullptr, seconds);
+    return guarded([&]() -> int { return pool_encode_body(p, rgb, W, H, n_frames, flags, out, out_stride, bits, seconds); });
 }
 
 // ---- the reference's stage functions, one by one ---------------------------------------
@@ -1779,7 +2012,7 @@ struct Stage {
 }  // namespace
 extern "C" {
 
-int mi355_jpeg_stage_csc(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W, uint32_t H) {
+static int stage_csc_body(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W, uint32_t H){
     if (!img || !W || !H) return MI355_E_ARG;
     Stage st(c);
     const size_t n = (size_t)W * H * 3;
@@ -1789,8 +2022,11 @@ int mi355_jpeg_stage_csc(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W, uint32_t H
     st.down(img, d, n);
     return st.e;
 }
+int mi355_jpeg_stage_csc(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W, uint32_t H) {
+    return guarded([&]() -> int { return stage_csc_body(c, img, W, H); });
+}
 
-int mi355_jpeg_stage_cds(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W, uint32_t H) {
+static int stage_cds_body(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W, uint32_t H){
     if (!img || !W || !H) return MI355_E_ARG;
     Stage st(c);
     const size_t n = (size_t)W * H * 3;
@@ -1800,9 +2036,12 @@ int mi355_jpeg_stage_cds(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W, uint32_t H
     st.down(img, d, n);
     return st.e;
 }
+int mi355_jpeg_stage_cds(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W, uint32_t H) {
+    return guarded([&]() -> int { return stage_cds_body(c, img, W, H); });
+}
 
-int mi355_jpeg_stage_copy_larger(mi355_jpeg_ctx* c, const uint8_t* src, uint32_t W, uint32_t H, uint8_t* dst, uint32_t W8,
-                                 uint32_t H8) {
+static int stage_copy_larger_body(mi355_jpeg_ctx* c, const uint8_t* src, uint32_t W, uint32_t H, uint8_t* dst, uint32_t W8,
+                                 uint32_t H8){
     if (!src || !dst || !W || !H || W8 < W || H8 < H) return MI355_E_ARG;
     Stage st(c);
     const size_t ns = (size_t)W * H * 3, nd = (size_t)W8 * H8 * 3;
@@ -1814,8 +2053,12 @@ int mi355_jpeg_stage_copy_larger(mi355_jpeg_ctx* c, const uint8_t* src, uint32_t
     st.down(dst, dd, nd);
     return st.e;
 }
+int mi355_jpeg_stage_copy_larger(mi355_jpeg_ctx* c, const uint8_t* src, uint32_t W, uint32_t H, uint8_t* dst, uint32_t W8,
+                                 uint32_t H8) {
+    return guarded([&]() -> int { return stage_copy_larger_body(c, src, W, H, dst, W8, H8); });
+}
 
-int mi355_jpeg_stage_mirror_pad(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W8, uint32_t H8, uint32_t oldW, uint32_t oldH) {
+static int stage_mirror_pad_body(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W8, uint32_t H8, uint32_t oldW, uint32_t oldH){
     if (!img || !oldW || !oldH || W8 < oldW || H8 < oldH) return MI355_E_ARG;
     if (W8 - oldW > oldW || H8 - oldH > oldH) return MI355_E_ARG;  // the reference underflows `oldWidth - diff` there
     Stage st(c);
@@ -1826,8 +2069,11 @@ int mi355_jpeg_stage_mirror_pad(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W8, ui
     st.down(img, d, n);
     return st.e;
 }
+int mi355_jpeg_stage_mirror_pad(mi355_jpeg_ctx* c, uint8_t* img, uint32_t W8, uint32_t H8, uint32_t oldW, uint32_t oldH) {
+    return guarded([&]() -> int { return stage_mirror_pad_body(c, img, W8, H8, oldW, oldH); });
+}
 
-int mi355_jpeg_stage_to_double(mi355_jpeg_ctx* c, const uint8_t* src, double* dst, uint32_t W, uint32_t H) {
+static int stage_to_double_body(mi355_jpeg_ctx* c, const uint8_t* src, double* dst, uint32_t W, uint32_t H){
     if (!src || !dst || !W || !H) return MI355_E_ARG;
     Stage st(c);
     const size_t n = (size_t)W * H * 3;
@@ -1838,8 +2084,11 @@ int mi355_jpeg_stage_to_double(mi355_jpeg_ctx* c, const uint8_t* src, double* ds
     st.down(dst, dd, n * sizeof(double));
     return st.e;
 }
+int mi355_jpeg_stage_to_double(mi355_jpeg_ctx* c, const uint8_t* src, double* dst, uint32_t W, uint32_t H) {
+    return guarded([&]() -> int { return stage_to_double_body(c, src, dst, W, H); });
+}
 
-int mi355_jpeg_stage_subtract(mi355_jpeg_ctx* c, double* img, uint32_t W, uint32_t H, double value) {
+static int stage_subtract_body(mi355_jpeg_ctx* c, double* img, uint32_t W, uint32_t H, double value){
     if (!img || !W || !H) return MI355_E_ARG;
     Stage st(c);
     const size_t n = (size_t)W * H * 3;
@@ -1849,8 +2098,11 @@ int mi355_jpeg_stage_subtract(mi355_jpeg_ctx* c, double* img, uint32_t W, uint32
     st.down(img, d, n * sizeof(double));
     return st.e;
 }
+int mi355_jpeg_stage_subtract(mi355_jpeg_ctx* c, double* img, uint32_t W, uint32_t H, double value) {
+    return guarded([&]() -> int { return stage_subtract_body(c, img, W, H, value); });
+}
 
-int mi355_jpeg_stage_dct(mi355_jpeg_ctx* c, double* img, uint32_t W8, uint32_t H8) {
+static int stage_dct_body(mi355_jpeg_ctx* c, double* img, uint32_t W8, uint32_t H8){
     if (!img || !W8 || !H8 || (W8 & 7) || (H8 & 7)) return MI355_E_ARG;
     Stage st(c);
     const size_t n = (size_t)W8 * H8 * 3;
@@ -1860,9 +2112,12 @@ int mi355_jpeg_stage_dct(mi355_jpeg_ctx* c, double* img, uint32_t W8, uint32_t H
     st.down(img, d, n * sizeof(double));
     return st.e;
 }
+int mi355_jpeg_stage_dct(mi355_jpeg_ctx* c, double* img, uint32_t W8, uint32_t H8) {
+    return guarded([&]() -> int { return stage_dct_body(c, img, W8, H8); });
+}
 
-int mi355_jpeg_stage_quantize(mi355_jpeg_ctx* c, double* img, uint32_t W8, uint32_t H8, const uint32_t qlum[64],
-                              const uint32_t qchrom[64]) {
+static int stage_quantize_body(mi355_jpeg_ctx* c, double* img, uint32_t W8, uint32_t H8, const uint32_t qlum[64],
+                              const uint32_t qchrom[64]){
     if (!img || !qlum || !qchrom || !W8 || !H8 || (W8 & 7) || (H8 & 7)) return MI355_E_ARG;
     double q[128];
     for (int i = 0; i < 64; ++i) {
@@ -1879,8 +2134,12 @@ int mi355_jpeg_stage_quantize(mi355_jpeg_ctx* c, double* img, uint32_t W8, uint3
     st.down(img, d, n * sizeof(double));
     return st.e;
 }
+int mi355_jpeg_stage_quantize(mi355_jpeg_ctx* c, double* img, uint32_t W8, uint32_t H8, const uint32_t qlum[64],
+                              const uint32_t qchrom[64]) {
+    return guarded([&]() -> int { return stage_quantize_body(c, img, W8, H8, qlum, qchrom); });
+}
 
-int mi355_jpeg_stage_blocks(mi355_jpeg_ctx* c, const double* img, uint32_t W8, uint32_t H8, int32_t* linear) {
+static int stage_blocks_body(mi355_jpeg_ctx* c, const double* img, uint32_t W8, uint32_t H8, int32_t* linear){
     if (!img || !linear || !W8 || !H8 || (W8 & 7) || (H8 & 7)) return MI355_E_ARG;
     Stage st(c);
     const size_t n = (size_t)W8 * H8 * 3;
@@ -1891,8 +2150,11 @@ int mi355_jpeg_stage_blocks(mi355_jpeg_ctx* c, const double* img, uint32_t W8, u
     st.down(linear, dl, n * sizeof(int));
     return st.e;
 }
+int mi355_jpeg_stage_blocks(mi355_jpeg_ctx* c, const double* img, uint32_t W8, uint32_t H8, int32_t* linear) {
+    return guarded([&]() -> int { return stage_blocks_body(c, img, W8, H8, linear); });
+}
 
-int mi355_jpeg_stage_zigzag(mi355_jpeg_ctx* c, const int32_t* linear, int32_t* zigzag, uint32_t rows) {
+static int stage_zigzag_body(mi355_jpeg_ctx* c, const int32_t* linear, int32_t* zigzag, uint32_t rows){
     if (!linear || !zigzag || !rows) return MI355_E_ARG;
     Stage st(c);
     const size_t n = (size_t)rows * 64 * sizeof(int);
@@ -1903,8 +2165,11 @@ int mi355_jpeg_stage_zigzag(mi355_jpeg_ctx* c, const int32_t* linear, int32_t* z
     st.down(zigzag, dz, n);
     return st.e;
 }
+int mi355_jpeg_stage_zigzag(mi355_jpeg_ctx* c, const int32_t* linear, int32_t* zigzag, uint32_t rows) {
+    return guarded([&]() -> int { return stage_zigzag_body(c, linear, zigzag, rows); });
+}
 
-int mi355_jpeg_stage_rle(mi355_jpeg_ctx* c, const int32_t* zigzag, uint32_t rows, int32_t* pairs, uint32_t* counts) {
+static int stage_rle_body(mi355_jpeg_ctx* c, const int32_t* zigzag, uint32_t rows, int32_t* pairs, uint32_t* counts){
     if (!zigzag || !pairs || !counts || !rows) return MI355_E_ARG;
     Stage st(c);
     int* dz = (int*)st.buf(0, (size_t)rows * 64 * sizeof(int));
@@ -1916,9 +2181,12 @@ int mi355_jpeg_stage_rle(mi355_jpeg_ctx* c, const int32_t* zigzag, uint32_t rows
     st.down(pairs, dp, (size_t)rows * 128 * sizeof(int));
     return st.e;
 }
+int mi355_jpeg_stage_rle(mi355_jpeg_ctx* c, const int32_t* zigzag, uint32_t rows, int32_t* pairs, uint32_t* counts) {
+    return guarded([&]() -> int { return stage_rle_body(c, zigzag, rows, pairs, counts); });
+}
 
-int mi355_jpeg_stage_huffman(mi355_jpeg_ctx* c, const int32_t* zigzag, const int32_t* pairs, const uint32_t* counts,
-                             uint32_t N, uint8_t* out, size_t cap, uint64_t* bits) {
+static int stage_huffman_body(mi355_jpeg_ctx* c, const int32_t* zigzag, const int32_t* pairs, const uint32_t* counts,
+                             uint32_t N, uint8_t* out, size_t cap, uint64_t* bits){
     if (!zigzag || !pairs || !counts || !out || !bits || !N) return MI355_E_ARG;
     const size_t rows = (size_t)N * 3;
     for (size_t r = 0; r < rows; ++r)
@@ -1952,34 +2220,46 @@ int mi355_jpeg_stage_huffman(mi355_jpeg_ctx* c, const int32_t* zigzag, const int
     st.down(out, dm + off_out, nb);
     return st.e;
 }
+int mi355_jpeg_stage_huffman(mi355_jpeg_ctx* c, const int32_t* zigzag, const int32_t* pairs, const uint32_t* counts,
+                             uint32_t N, uint8_t* out, size_t cap, uint64_t* bits) {
+    return guarded([&]() -> int { return stage_huffman_body(c, zigzag, pairs, counts, N, out, cap, bits); });
+}
 
 // ---- measurement ---------------------------------------------------------------
 
-int mi355_jpeg_last_call_launches(mi355_jpeg_ctx* c, uint32_t* n) {
+static int last_call_launches_body(mi355_jpeg_ctx* c, uint32_t* n){
     if (!c || !n) return MI355_E_ARG;
     *n = c->last_launches;
     return MI355_OK;
 }
+int mi355_jpeg_last_call_launches(mi355_jpeg_ctx* c, uint32_t* n) {
+    return guarded([&]() -> int { return last_call_launches_body(c, n); });
+}
 
-int mi355_jpeg_screen_stats(mi355_jpeg_ctx* c, void* stream, mi355_jpeg_screen_counts* out, int reset) {
+static int screen_stats_body(mi355_jpeg_ctx* c, void* stream, mi355_jpeg_screen_counts* out, int reset){
     if (!c || !out) return MI355_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     (void)stream;
     // every stream of the device, the library's side stream included: kernels still running anywhere would keep adding
     // to the counters while they are read or reset
     HIP_TRY(hipDeviceSynchronize());
-    unsigned long long h[2] = {0, 0};
+    unsigned long long h[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(h, c->d_stats, sizeof h, hipMemcpyDeviceToHost));
     out->second_looks = h[0];
     out->exact_units = h[1];
+    out->rewalked_units = h[2];
+    out->general_passes = h[3];
     if (reset) {
         HIP_TRY(hipMemset(c->d_stats, 0, sizeof h));
         HIP_TRY(hipStreamSynchronize(nullptr));
     }
     return MI355_OK;
 }
+int mi355_jpeg_screen_stats(mi355_jpeg_ctx* c, void* stream, mi355_jpeg_screen_counts* out, int reset) {
+    return guarded([&]() -> int { return screen_stats_body(c, stream, out, reset); });
+}
 
-int mi355_jpeg_set_profiling(mi355_jpeg_ctx* c, int mode) {
+static int set_profiling_body(mi355_jpeg_ctx* c, int mode){
     if (!c || mode < 0 || mode > 2) return MI355_E_ARG;
     // stage probes and the entropy-only entry point do not open event sets: drop
     // half-recorded state by starting over
@@ -1988,15 +2268,21 @@ int mi355_jpeg_set_profiling(mi355_jpeg_ctx* c, int mode) {
     c->ev_open = false;
     return MI355_OK;
 }
+int mi355_jpeg_set_profiling(mi355_jpeg_ctx* c, int mode) {
+    return guarded([&]() -> int { return set_profiling_body(c, mode); });
+}
 
-int mi355_jpeg_last_timings(mi355_jpeg_ctx* c, mi355_jpeg_timings* t) {
+static int last_timings_body(mi355_jpeg_ctx* c, mi355_jpeg_timings* t){
     if (!c || !t) return MI355_E_ARG;
     memset(t, 0, sizeof *t);
     if (!c->profiling || c->ev_used == 0) return MI355_E_ARG;
     return timings_of(c, c->ev_pool[c->ev_used - 1], t);
 }
+int mi355_jpeg_last_timings(mi355_jpeg_ctx* c, mi355_jpeg_timings* t) {
+    return guarded([&]() -> int { return last_timings_body(c, t); });
+}
 
-int mi355_jpeg_profile_summary(mi355_jpeg_ctx* c, mi355_jpeg_timings* sum, uint32_t* calls) {
+static int profile_summary_body(mi355_jpeg_ctx* c, mi355_jpeg_timings* sum, uint32_t* calls){
     if (!c || !sum || !calls) return MI355_E_ARG;
     memset(sum, 0, sizeof *sum);
     *calls = 0;
@@ -2013,6 +2299,9 @@ int mi355_jpeg_profile_summary(mi355_jpeg_ctx* c, mi355_jpeg_timings* sum, uint3
     sum->emit_ms = (float)acc[3], sum->total_ms = (float)acc[4];
     *calls = (uint32_t)c->ev_used;
     return MI355_OK;
+}
+int mi355_jpeg_profile_summary(mi355_jpeg_ctx* c, mi355_jpeg_timings* sum, uint32_t* calls) {
+    return guarded([&]() -> int { return profile_summary_body(c, sum, calls); });
 }
 
 }  // extern "C"

@@ -214,7 +214,7 @@ def test_abi_exports_every_declared_symbol(jpeg):
     for s in syms:
         assert hasattr(L, s), "libmi355jpeg.so does not export " + s
     assert sorted(jpeg.ABI_SYMBOLS) == syms
-    assert L.mi355_jpeg_abi_version() == 3
+    assert L.mi355_jpeg_abi_version() == 4
 
 
 def test_host_helpers_without_a_gpu(jpeg):
@@ -283,3 +283,28 @@ def test_exactness_knobs_are_refused_before_any_device_is_touched(monkeypatch):
         monkeypatch.setenv(name, v)
         assert create() == base, (name, v)
         monkeypatch.delenv(name)
+
+
+def test_no_exception_crosses_the_c_abi(jpeg):
+    """VERDICT r3 item 5 / SURVEY §8 (b): an allocation that fails inside an entry point comes back as MI355_E_ALLOC, not as
+    std::terminate in the caller's process.  In a child process under RLIMIT_AS, mi355_jpeg_pool_create is asked for
+    2^29 workers: the copy of the id list (2 GiB) throws std::bad_alloc before a device is looked at, so this runs with
+    or without a GPU."""
+    import subprocess
+    import sys
+    prog = r"""
+import ctypes as C, importlib, os, resource, sys
+sys.path.insert(0, %r)
+jpeg = importlib.import_module("jpeg-encoder-opencl_amd")
+L = jpeg.lib()
+with open("/proc/self/statm") as f:
+    vm = int(f.read().split()[0]) * os.sysconf("SC_PAGE_SIZE")
+resource.setrlimit(resource.RLIMIT_AS, (vm + (512 << 20), resource.getrlimit(resource.RLIMIT_AS)[1]))
+ids = (C.c_int * 4)(0, 0, 0, 0)
+h = C.c_void_p()
+print("RC", L.mi355_jpeg_pool_create(ids, 1 << 29, C.byref(h)), bool(h))
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stderr[-800:])
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RC ")][0].split()
+    assert int(line[1]) == jpeg.E_ALLOC and line[2] == "False", line

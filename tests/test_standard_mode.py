@@ -439,3 +439,29 @@ def test_gpu_tiny_420_noise_at_q100_fits_the_flag_aware_bound(jpeg, enc, flags_e
                 assert got == ol.jfif_frame(o.bits, o.n_bits, W, H, ql, qc, 1)
             assert pil_decode(got).shape == rgb.shape
     enc.set_quality(50)
+
+
+@pytest.mark.gpu
+def test_gpu_standard_420_tiled_fruit_golden(jpeg, enc):
+    """SURVEY §8(d)'s natural-statistics input in the decodable mode: fruit.ppm tiled to 3840x2160, 4:2:0, q50, against the
+    fixture the checker wrote (tests/golden/cases.json, tools/make_golden.py --tiled-fruit) -- the same record bench.py
+    gates its `other_configs` leg on -- and through Pillow: the file decodes, and to within 45 dB of Pillow's own encode
+    of the same pixels with the same tables... (PSNR of our decode against Pillow's decode of its own file)."""
+    import hashlib
+    import json
+    from conftest import case_input
+    case = [c for c in json.load(open(os.path.join(GOLD, "cases.json"))) if c["name"] == "std420_fruit_tiled_3840x2160_q50"][0]
+    rgb = case_input(case)
+    ql, qc = ol.quant_tables(case["quality"])
+    enc.set_quant(ql, qc)
+    flags = jpeg.F_STANDARD | jpeg.F_420
+    bits, nb = enc.encode_scan(rgb, flags, cap=(case["n_bits"] + 7) // 8 + 64)
+    assert nb[0] == case["n_bits"]
+    assert hashlib.sha256(bits[0][:(nb[0] + 7) // 8].tobytes()).hexdigest() == case["sha256_packed_bits"]
+    ours = pil_decode(enc.encode_jfif(rgb, flags)).astype(np.float64)
+    theirs = pil_decode(pil_encode(rgb, ql, qc, subsample=1)).astype(np.float64)
+    src = rgb.astype(np.float64)
+    psnr = lambda a, b: 10 * np.log10(255.0 ** 2 / np.mean((a - b) ** 2))
+    # both files are the same picture at the same quality: equally far from the source, and close to each other
+    assert abs(psnr(ours, src) - psnr(theirs, src)) < 0.15, (psnr(ours, src), psnr(theirs, src))
+    assert psnr(ours, theirs) >= 45.0, psnr(ours, theirs)

@@ -58,10 +58,45 @@ def case_record(name, rgb, quality, cds_on, stages=False):
     return rec, r
 
 
+def tiled_fruit(W=3840, H=2160):
+    """src[(y mod 254) * 253 + (x mod 253)] of data/fruit.ppm."""
+    fruit = ol.read_ppm(os.path.join(GOLD, "fruit.ppm"))
+    yy, xx = np.arange(H) % fruit.shape[0], np.arange(W) % fruit.shape[1]
+    return np.ascontiguousarray(fruit[yy][:, xx])
+
+
+def add_tiled_fruit():
+    assert ol.ref() is not None, "build oracle/_ref first (make -C oracle)"
+    path = os.path.join(GOLD, "cases.json")
+    cases = [c for c in json.load(open(path)) if not c["name"].startswith(("fruit_tiled_", "std420_fruit_tiled_"))]
+    rgb = tiled_fruit()
+    rec = case_record("fruit_tiled_3840x2160_q50_cds", rgb, 50, True)[0]
+    rec["big"] = True
+    cases.append(rec)
+    print(rec["name"], rec["n_bits"], rec["sha256_ascii_bits"])
+    ql, qc = ol.quant_tables(50)
+    o = ol.oracle_std_encode(rgb, ql, qc, 0, 1)
+    rec2 = {"name": "std420_fruit_tiled_3840x2160_q50", "W": 3840, "H": 2160, "quality": 50, "flags": "MI355_F_STANDARD|MI355_F_420",
+            "n_bits": int(o.n_bits), "sha256_packed_bits": hashlib.sha256(o.bits[:(o.n_bits + 7) // 8].tobytes()).hexdigest(),
+            "source": "oracle/jpeg_oracle.c orc_std_encode (the checker of standard mode: parity unpinned by the reference)",
+            "big": True, "standard": True}
+    cases.append(rec2)
+    print(rec2["name"], rec2["n_bits"], rec2["sha256_packed_bits"])
+    with open(path, "w") as f:
+        json.dump(cases, f, indent=1)
+    print("wrote", len(cases), "cases")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true")
+    ap.add_argument("--tiled-fruit", action="store_true",
+                    help="only ADD the natural-statistics cases of SURVEY §8(d) to the existing cases.json: fruit.ppm tiled to "
+                         "3840x2160, strict q50 from the reference build (SURVEY Appendix B: 39 146 255 bits, a23fc925...) and "
+                         "standard 4:2:0 q50 from the checker (that mode is not a behaviour of the reference)")
     args = ap.parse_args()
+    if args.tiled_fruit:
+        return add_tiled_fruit()
     assert ol.ref() is not None, "build oracle/_ref first (make -C oracle)"
     os.makedirs(GOLD, exist_ok=True)
     L = ol.ref()
