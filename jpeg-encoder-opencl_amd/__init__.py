@@ -134,13 +134,16 @@ def lib():
         L.mi355_jpeg_pool_workers.argtypes = [vp]
         L.mi355_jpeg_pool_set_quant.argtypes = [vp, vp, vp]
         L.mi355_jpeg_pool_set_quality.argtypes = [vp, C.c_int]
-        L.mi355_jpeg_pool_set_huffman.argtypes = [vp, C.c_int, C.POINTER(HuffTable)]
+        if hasattr(L, "mi355_jpeg_pool_set_huffman"):  # (absent from an ABI 3 build loaded through MI355_JPEG_LIB for an A/B run)
+            L.mi355_jpeg_pool_set_huffman.argtypes = [vp, C.c_int, C.POINTER(HuffTable)]
         L.mi355_jpeg_pool_encode.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, u64p, C.POINTER(C.c_double)]
         L.mi355_jpeg_pool_encode_ex.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, u64p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.mi355_jpeg_pool_register.argtypes = [vp, vp, sz]
         L.mi355_jpeg_pool_unregister.argtypes = [vp, vp]
         L.mi355_jpeg_pool_debug_counts.argtypes = [vp, u64p]
         for name in ABI_SYMBOLS:  # fail at load time, not at first use, if a symbol is missing
+            if os.environ.get("MI355_JPEG_LIB") and name == "mi355_jpeg_pool_set_huffman":
+                continue  # an older build in an A/B run
             getattr(L, name)
         _lib = L
     return _lib

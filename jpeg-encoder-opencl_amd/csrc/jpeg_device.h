@@ -18,6 +18,7 @@ struct Geom {
                             // (four luma quarter-tiles of 16 MCUs, then Cb, then Cr)
     uint32_t nmx;           // 4:2:0 only: MCUs (16x16) per row = W8/16; there N = MCUs per frame,
                             // W8/H8 are multiples of 16 and a tile is 64 MCUs = 384 units of the scan
+    uint32_t nbx_mul, nbx_shift;  // b / nbx = (mulhi(b, nbx_mul) + b) >> nbx_shift for b < 2^31 (round-up reciprocal, make_geom)
     uint64_t frame_stride;  // bytes between frames = W*H*3
 };
 inline bool is420(const Geom& g) { return g.passes == 6; }

@@ -86,7 +86,9 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
     __shared__ uint32_t s_lut2[2][kLut2Words];  // (value,run) symbol tables
     __shared__ uint32_t s_dc[2][16];      // DC tables
 
-    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
+    // (the wave index through readfirstlane: the compiler cannot know that tid >> 6 is wave-uniform, and everything derived
+    // from it -- the pass coordinates, frame bases, table rows -- would be formed per lane on the VALU)
+    const uint32_t tid = threadIdx.x, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63, n = lane & 15, gq = lane >> 4;
     uint32_t* s_tbuf = s_tbuf_all[wv];
     uint32_t* s_slot = s_slot_all[wv];
     uint32_t* s_mlo = s_mask_all[wv][0];
@@ -147,24 +149,45 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
     // instruction, and because vmcnt retires in issue order it does not wait behind this pass's scattered string stores.
     struct Pass {
         uint32_t frame, tile, chan;
-        uint32_t bxy[4];  // block (or MCU) coordinates of this lane's four units: x | y << 16 (packed: registers)
+        // block (or MCU) coordinates of this lane's four units: x | y << 16 (packed: registers).  Four scalars, not an
+        // array: an array member kept the struct in memory (the optimiser's 20-byte alloca was then promoted to LDS --
+        // 5 KB per workgroup, enough to push the tail kernels off the CU: -25 % on batches)
+        uint32_t b0, b1, b2, b3;
         bool fast;
-    };
-    auto locate = [&](uint32_t p) -> Pass {
-        Pass ps;
-        uint32_t frame, tile, chan;
-        if (xcd_map) {
-            const uint32_t pf = tiles_x * kPasses;
-            frame = p / pf;
-            const uint32_t q = p - frame * pf;
-            tile = (q / kPasses) * 8u + xcd;
-            chan = q % kPasses;
-        } else {
-            frame = p / per_frame;
-            const uint32_t q = p - frame * per_frame;
-            tile = q / kPasses;
-            chan = q % kPasses;
+        __device__ __forceinline__ uint32_t bxy(int j) const { return j == 0 ? b0 : (j == 1 ? b1 : (j == 2 ? b2 : b3)); }
+        __device__ __forceinline__ void set_bxy(int j, uint32_t v) {
+            if (j == 0) b0 = v;
+            else if (j == 1) b1 = v;
+            else if (j == 2) b2 = v;
+            else b3 = v;
         }
+    };
+    // The wave's passes are p = pstart, pstart + pstep, ...; p = (frame * T + tq) * kPasses + chan with T = the tiles this
+    // wave's XCD owns per frame (all of them without the XCD map) and tile = tq * 8 + xcd (tq without it).  (frame, tq,
+    // chan) advance by a constant, with carries: no division per pass.
+    const uint32_t T = xcd_map ? tiles_x : g.tiles;
+    const uint32_t step_tq = pstep / kPasses, step_chan = pstep % kPasses;
+    struct Cursor {
+        uint32_t frame, tq, chan;
+    };
+    auto cursor_at = [&](uint32_t p) -> Cursor {  // (once per wave)
+        const uint32_t pf = T * kPasses;
+        Cursor c;
+        c.frame = p / pf;
+        const uint32_t q = p - c.frame * pf;
+        c.tq = q / kPasses;
+        c.chan = q % kPasses;
+        return c;
+    };
+    auto advance = [&](Cursor& c) {
+        c.chan += step_chan;
+        c.tq += step_tq;
+        if (c.chan >= kPasses) c.chan -= kPasses, ++c.tq;
+        while (c.tq >= T) c.tq -= T, ++c.frame;
+    };
+    auto locate = [&](const Cursor& cs) -> Pass {
+        Pass ps;
+        const uint32_t frame = cs.frame, chan = cs.chan, tile = xcd_map ? cs.tq * 8u + xcd : cs.tq;
         const bool luma420 = S420 && chan < 4u;
 
         // block coordinates of this lane's four blocks (16j + n), and whether the whole tile
@@ -184,10 +207,10 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
                 }
                 if (luma420) {
                     const uint32_t lx = 2 * mx + (n & 1), ly = 2 * my + ((n >> 1) & 1);
-                    ps.bxy[j] = lx | (ly << 16);
+                    ps.set_bxy(j, lx | (ly << 16));
                     interior = interior && (lx * 8 + 8 <= g.W) && (ly * 8 + 8 <= g.H);
                 } else {
-                    ps.bxy[j] = mx | (my << 16);
+                    ps.set_bxy(j, mx | (my << 16));
                     interior = interior && (mx * 16 + 16 <= g.W) && (my * 16 + 16 <= g.H);
                 }
                 m += step;
@@ -197,6 +220,23 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
                     ++my;
                 }
             }
+        } else if (g.fast_rows && g.nbx >= 64u && tile * 64u + 64u <= g.N) {
+            // The common case -- rows of whole blocks (W % 8 == 0), at least 64 blocks per row, a full tile: the tile's origin
+            // by one scalar division (multiply-high by the host's reciprocal), the lanes' blocks by conditional subtraction,
+            // and the tile lies inside the image iff its LAST block's row does.
+            const uint32_t t0 = tile << 6;
+            const uint32_t ty = (__umulhi(t0, g.nbx_mul) + t0) >> g.nbx_shift, tx = t0 - ty * g.nbx;
+            const uint32_t y63 = (__umulhi(t0 + 63u, g.nbx_mul) + t0 + 63u) >> g.nbx_shift;
+            uint32_t bx = tx + n, by = ty;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool wrap = bx >= g.nbx;
+                bx -= wrap ? g.nbx : 0u;
+                by += wrap ? 1u : 0u;
+                ps.set_bxy(j, bx | (by << 16));
+                bx += 16;
+            }
+            interior = y63 * 8u + 8u <= g.H;
         } else {
             uint32_t b = tile * 64 + n;
             uint32_t by = b / g.nbx, bx = b - by * g.nbx;
@@ -207,7 +247,7 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
                     bx = g.nbx - 1;
                     by = g.N / g.nbx - 1;
                 }
-                ps.bxy[j] = bx | (by << 16);
+                ps.set_bxy(j, bx | (by << 16));
                 interior = interior && (bx * 8 + 8 <= g.W) && (by * 8 + 8 <= g.H);
                 bx += 16;
                 while (bx >= g.nbx) {
@@ -216,7 +256,7 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
                 }
             }
         }
-        ps.fast = g.fast_rows && __all(interior);
+        ps.fast = g.fast_rows && !wave_any(!interior);
         ps.frame = frame, ps.tile = tile, ps.chan = chan;
         return ps;
     };
@@ -231,14 +271,16 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
             // the pass's colour-conversion fragments travel with its first rows: requested before the walk of the pass in
             // front, they do not queue behind that pass's string stores (vmcnt retires in issue order)
             load_csc_fragments(sp, lane, (int)ps.chan * 4, F);
-            load_std_rowpair(pf, g, ps.bxy[0] & 0xffffu, ps.bxy[0] >> 16, gq, Xn);
+            load_std_rowpair(pf, g, ps.b0 & 0xffffu, ps.b0 >> 16, gq, Xn);
         } else {
-            if (!chroma420) load_raw_rowpair(pf, g, ps.bxy[0] & 0xffffu, ps.bxy[0] >> 16, gq, raw);
+            if (!chroma420) load_raw_rowpair(pf, g, ps.b0 & 0xffffu, ps.b0 >> 16, gq, raw);
         }
     };
     Pass cur{}, nxt{};
+    Cursor cs{0, 0, 0};
     if (pstart < pairs_total) {
-        cur = locate(pstart);
+        cs = cursor_at(pstart);
+        cur = locate(cs);
         request_first_rows(cur);
     }
     for (uint32_t p = pstart; p < pairs_total; p += pstep) {
@@ -274,14 +316,14 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
         uint32_t dcsum = 0;  // sample sum of the block whose coefficient 0 this lane will form
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t bx = cur.bxy[j] & 0xffffu, by = cur.bxy[j] >> 16;
+            const uint32_t bx = cur.bxy(j) & 0xffffu, by = cur.bxy(j) >> 16;
             uint32_t pk[4];  // 16 samples; on_mfma: as sample - 128 (int8), else unsigned
             if (on_mfma) {
                 if constexpr (kCscMfma) {
                     // (one buffer: the next row pair lands during the quantiser)
                     if (comp) std_rowpair_mfma<true>(Xn, F, pk);
                     else std_rowpair_mfma<false>(Xn, F, pk);
-                    if (j < 3) load_std_rowpair(f, g, cur.bxy[j + 1] & 0xffffu, cur.bxy[j + 1] >> 16, gq, Xn);
+                    if (j < 3) load_std_rowpair(f, g, cur.bxy(j + 1) & 0xffffu, cur.bxy(j + 1) >> 16, gq, Xn);
                 }
             } else if (chroma420) {
                 if constexpr (S420) {  // rows 2gq, 2gq+1 of the MCU's 8x8 chroma block <- pixel rows 4gq .. 4gq+3
@@ -303,7 +345,7 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
                 uint32_t rp[12];
 #pragma unroll
                 for (int i = 0; i < 12; ++i) rp[i] = raw[i];
-                if (j < 3) load_raw_rowpair(f, g, cur.bxy[j + 1] & 0xffffu, cur.bxy[j + 1] >> 16, gq, raw);  // (two pairs in flight: -1 %)
+                if (j < 3) load_raw_rowpair(f, g, cur.bxy(j + 1) & 0xffffu, cur.bxy(j + 1) >> 16, gq, raw);  // (two pairs in flight: -1 %)
                 if (comp == 0) convert_rowpair<0, STD>(rp, false, pk);
                 else if (comp == 1) convert_rowpair<1, STD>(rp, avg, pk);
                 else convert_rowpair<2, STD>(rp, avg, pk);
@@ -387,7 +429,8 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
             STAMP(6);
         }
         if (p + pstep < pairs_total) {  // wave-uniform
-            nxt = locate(p + pstep);
+            advance(cs);
+            nxt = locate(cs);
             request_first_rows(nxt);
         }
         {

@@ -454,6 +454,15 @@ int make_geom(uint32_t W, uint32_t H, uint32_t flags, const void* base, Geom* g)
     g->N = (W8 / A) * (H8 / A);  // 8x8 blocks per channel, or 16x16 MCUs in 4:2:0
     g->tiles = (g->N + 63) / 64;
     g->flags = flags;
+    {   // reciprocal of nbx: M = floor(2^(32 + s) / d) + 1 with s = ceil(log2 d); q = (mulhi(n, M - 2^32) + n) >> s is n / d
+        // for every n the sum does not overflow (n < 2^31; block indices are below 2^26)
+        const uint32_t d = g->nbx;
+        uint32_t sh = 0;
+        while ((1u << sh) < d) ++sh;
+        const unsigned __int128 M = (((unsigned __int128)1 << (32 + sh)) / d) + 1;
+        g->nbx_mul = (uint32_t)(M - ((unsigned __int128)1 << 32));
+        g->nbx_shift = sh;
+    }
     g->frame_stride = (uint64_t)W * H * 3;
     // the fast row loads use 32-bit byte offsets inside a frame (load_raw_rowpair)
     g->fast_rows = (W % 8 == 0) && (((uintptr_t)base & 7u) == 0) && ((uint64_t)W * H * 3u < (1ull << 32));

@@ -907,15 +907,15 @@ def test_eight_workers_on_a_scaled_down_config4_share(jpeg):
         e2.sync()
         h_rgb[lo:lo + 32].copy_(d_tmp)
     del d_tmp
-    # frame 77: a smooth frame with one extreme block (AC magnitude >= 128 at q50), and an AC-luma table without its
-    # size-8 entries: noise at q50 stays below 32, so only frame 77 meets the hole
+    # frame 77: a smooth frame with one extreme block (AC magnitude 64..127 at q50), and an AC-luma table without its
+    # size-7 entries: noise at q50 stays below 32, so only frame 77 meets the hole
     yy, xx = np.mgrid[0:H, 0:W]
     odd = np.stack([(xx * 200 // W + yy * 40 // H), 60 + yy * 100 // H, 180 - xx * 80 // W], -1).astype(np.uint8)
     odd[:4, :8] = 255
     odd[4:8, :8] = 0
     o77 = ol.oracle_encode(odd, ql, qc, True, ol.KEEP_ZIGZAG)
     Nb = (W // 8) * (H // 8)
-    assert 128 <= np.abs(o77.zigzag[:Nb, 1:]).max() < 256
+    assert 64 <= np.abs(o77.zigzag[:Nb, 1:]).max() < 128
     h_rgb[77] = torch.from_numpy(odd)
     cap = 5 << 20
     h_out = torch.zeros((n, cap), dtype=torch.uint8)
@@ -927,7 +927,7 @@ def test_eight_workers_on_a_scaled_down_config4_share(jpeg):
     pool.set_quality(50)
     code, length = e2.get_huffman(2)
     length = length.copy()
-    length[[(r << 4) | 8 for r in range(16)]] = 0
+    length[[(r << 4) | 7 for r in range(16)]] = 0
     tab = jpeg.HuffTable()
     for i in range(256):
         tab.code[i], tab.len[i] = int(code[i]), int(length[i])
@@ -951,7 +951,7 @@ def test_eight_workers_on_a_scaled_down_config4_share(jpeg):
         if g is not None:
             assert int(nb[f]) == g[0] and ascii_sha(h_out[f, :(g[0] + 7) // 8].numpy(), g[0]) == g[1], f
             checked += 1
-    assert checked >= 6
+    assert checked >= 4  # seeds 1..4 have goldens from the reference build
     print("pool, 8 workers on one GPU: %d x 4K in %.3f s = %.1f Gpixel/s incl. PCIe" % (n, secs.value, n * W * H / secs.value / 1e9))
     e2.close()
 
@@ -1054,13 +1054,13 @@ def test_per_frame_error_reporting(jpeg):
     for f in range(n):
         if f != 2:
             assert int(bits[f]) == ok[f].n_bits and np.array_equal(out[f, :(ok[f].n_bits + 7) // 8], ok[f].bits), f
-    # both causes in ONE call: frame 2 has the coefficient without a code, frame 6 (low-amplitude noise: many bits, no large
-    # coefficient) does not fit a slot sized for the smooth frames -> each frame carries its OWN verdict (ABI 3 labelled
+    # both causes in ONE call: frame 2 has the coefficient without a code, frame 6 (noise: no coefficient that large, but
+    # more bits than the slots sized for the smooth frames hold) -> each frame carries its OWN verdict (ABI 3 labelled
     # both with whichever cause came first)
     fr3 = fr2.copy()
-    fr3[6] = 112 + (ol.lcg_frame(W, H, 7) >> 3)
+    fr3[6] = ol.lcg_frame(W, H, 7)
     ok6 = ol.oracle_encode(fr3[6], ql, qc, True, ol.KEEP_ZIGZAG)
-    assert np.abs(ok6.zigzag[:, 1:]).max() < 512 and ok6.n_bits > 2 * max(o.n_bits for o in ok)
+    assert np.abs(ok6.zigzag[:, 1:]).max() < 512 and (ok6.n_bits + 7) // 8 > cap3
     d_rgb = torch.from_numpy(fr3).to(dev)
     d_out = torch.zeros((n, cap3), dtype=torch.uint8, device=dev)
     e2.encode_scan_device(d_rgb.data_ptr(), W, H, n, d_out.data_ptr(), cap3, d_bits.data_ptr())
