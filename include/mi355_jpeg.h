@@ -64,7 +64,14 @@ enum mi355_jpeg_status {
                                 matrix units, quotient by Q in fp32: the mode is defined by that arithmetic), colour conversion in
                                 15-bit fixed point (libjpeg's form: (c.RGB + half) >> 15, rows summing exactly), 4:4:4 unless MI355_F_420 (MI355_F_CDS is ignored), Annex K code tables proper (without
                                 the seven 17-bit entries of huffman.hpp:92-98), EOB omitted after a non-zero
-                                coefficient 63.  Files from mi355_jpeg_encode_jfif decode in libjpeg/PIL. */
+                                coefficient 63.  Files from mi355_jpeg_encode_jfif decode in libjpeg/PIL.
+                                CONTRACT of the quantised values (the one tolerance of this mode; tests/test_standard_mode.py
+                                asserts exactly this against an independent fp64 DCT): a coefficient equals
+                                round-half-away(DCT-II(samples - 128) / Q) computed in exact arithmetic, EXCEPT where
+                                that quotient lies within 2e-3 of a rounding tie (k + 1/2), where it may be the other
+                                neighbour (off by one).  Within that contract the value is DEFINED by the arithmetic above
+                                and is bit-identical across calls, batch shapes and library versions of the same ABI
+                                (ABI 3 and later; ABI 2 bitstreams of this mode differ). */
 #define MI355_F_420 4u       /* with MI355_F_STANDARD only (MI355_E_ARG otherwise): real 4:2:0 -- 16x16 MCUs of four
                                 luma blocks + one Cb + one Cr block (sampling 2x2,1x1,1x1 in SOF0), chroma = the conversion's
                                 linear form box-filtered over the 2x2 quad, rounded once; image mirror-padded to multiples of 16.

@@ -841,20 +841,23 @@ __device__ __forceinline__ void screen_quantise_f16(const v4i (&A)[kLookFragsF16
         if (lane == 0) atomicAdd(&sp.stats[0], 1ull);
         // second look: all five base-256 digits on the int8 instruction, exact in fp64
         const v4i B = v4i{(int)(pk[0] ^ 0x80808080u), (int)(pk[1] ^ 0x80808080u), (int)(pk[2] ^ 0x80808080u), (int)(pk[3] ^ 0x80808080u)};
-        v4i acc[kScreenLimbs];
-#pragma unroll
-        for (int l = 0; l < kScreenLimbs; ++l) {
+        // One digit at a time, most significant first (a rolled loop on purpose: five fragments and five accumulators live at
+        // once would set the register peak of the whole kernel for a path taken by one group in three hundred): y = y 256 + acc
+        // is exact in fp64 (|y| < 2^53).
+        double y2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int l = kScreenLimbs - 1; l >= 0; --l) {
             const uint4 t = sp.afrag[(mt * kScreenLimbs + l) * 64 + lane];
-            acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w}, B, v4i{0, 0, 0, 0}, 0, 0, 0);
+            const v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w}, B, v4i{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y2[r] = y2[r] * 256.0 + (double)acc[r];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (!(tt[r] > 0.0f)) {
                 // {s1, thr1, s2, thr2} of this position: read from memory, the second look is rare
                 const double* qc = sp.qconst + ((size_t)ct * 64 + 16 * mt + 4 * gq + r) * 4;
-                const double y1 = (double)acc[4][r] * 65536.0 + (double)(acc[3][r] * 256 + acc[2][r]);  // exact (< 2^37)
-                const double y2 = y1 * 65536.0 + (double)(acc[1][r] * 256 + acc[0][r]);                  // exact (< 2^53)
-                const double z = y2 * qc[2];
+                const double z = y2[r] * qc[2];
                 const double ta = __builtin_fabs(z) + 0.5;
                 const double fr = ta - __builtin_floor(ta);
                 const int nn = (int)ta;

@@ -89,6 +89,10 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
     // (the wave index through readfirstlane: the compiler cannot know that tid >> 6 is wave-uniform, and everything derived
     // from it -- the pass coordinates, frame bases, table rows -- would be formed per lane on the VALU)
     const uint32_t tid = threadIdx.x, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63, n = lane & 15, gq = lane >> 4;
+#ifndef MI355_OPAQUE_LANE
+#define MI355_OPAQUE_LANE 0
+#endif
+    const uint32_t lane_top = lane;
     uint32_t* s_tbuf = s_tbuf_all[wv];
     uint32_t* s_slot = s_slot_all[wv];
     uint32_t* s_mlo = s_mask_all[wv][0];
@@ -285,6 +289,13 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
     }
     for (uint32_t p = pstart; p < pairs_total; p += pstep) {
         STAMP(7);
+#if MI355_OPAQUE_LANE
+        // Lane-derived values (row addresses, table columns, masks) are formed again in every pass: left to itself the
+        // compiler hoists dozens of them out of the loop into registers that then live for the whole kernel.
+        uint32_t lane = lane_top;
+        asm volatile("" : "+v"(lane));
+        const uint32_t n = lane & 15, gq = lane >> 4;
+#endif
         const uint32_t frame = cur.frame, tile = cur.tile, chan = cur.chan;
         // `chan` is the pass; the colour component differs from it only in 4:2:0 (passes 0..3 = luma)
         const uint32_t comp = S420 ? (chan < 4u ? 0u : chan - 3u) : chan;

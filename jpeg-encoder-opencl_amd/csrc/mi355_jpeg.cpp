@@ -125,7 +125,7 @@ struct mi355_jpeg_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_half = nullptr, ev_side = nullptr;
     std::vector<hipEvent_t> ev_set;  // per workspace set: its last part's tail kernels are done
-    uint32_t batch_parts = 0xFFFFu;  // MI355_JPEG_BATCH_PARTS (1..8): upper limit of the parts of a batch (1 = off)
+    uint32_t batch_parts = 0xFFFFu;  // upper limit of the parts of a batch (default: none; MI355_JPEG_BATCH_PARTS sets 1..8, 1 = one part)
 
     uint32_t qlum[64], qchrom[64];
     mi355_huff_table huff[4];

@@ -100,14 +100,18 @@ int orc_entropy(const int32_t *zigzag, size_t n_blocks, uint8_t **bits, size_t *
 
 /* ---- standard mode --------------------------------------------
  * NOT a behaviour of the reference (parity unpinned by it): a decodable baseline
- * JPEG, 4:4:4, defined entirely in integer arithmetic so that the GPU path and
+ * JPEG, defined by a fixed sequence of integer and fp32 operations so that the GPU path and
  * this checker agree bit for bit:
  *   samples  15-bit fixed-point colour conversion in libjpeg's form (orc_std_csc:
  *            Y = (9798R+19235G+3735B+16384)>>15, Cb/Cr likewise with the "half - 1"
  *            constant; rows sum exactly, nothing to clamp), mirror padding as in strict mode;
- *   DCT      q[R] = round-half-away( sum_s dct[R][s]*(smp[s]-128) / (Q*2^39) ),
- *            dct = the true DCT-II rounded to 2^-39, rows in zig-zag order
- *            (tests/golden/std_dct_q39.i64, tools/gen_screen_tables.py);
+ *   DCT      the mode is DEFINED by its arithmetic (round 3), restated here operation for operation (std_block):
+ *            the top three base-256 digits of dct[R][s] (= the true DCT-II with 23 fractional bits; dct = the DCT-II
+ *            rounded to 2^-39, rows in zig-zag order: tests/golden/std_dct_q39.i64, tools/gen_screen_tables.py) applied
+ *            exactly in integers (acc4, acc3, acc2), t = 256 acc3 + acc2 and acc4 converted to float, fv = fmaf(acc4,
+ *            2^16, t), zf = fv * (float)(2^-23/Q), nearest integer of zf with ties to even; coefficient 0 is
+ *            round-half-away(sum / (8 Q0)) in integers.  Against round-half-away of the exact 2^-39 quotient this differs by
+ *            at most one, and only within 2e-3 of a tie (the contract in include/mi355_jpeg.h);
  *   entropy  Annex-K tables without the reference's seven 17-bit typos, EOB
  *            omitted when coefficient 63 is non-zero.
  * keep: ORC_KEEP_ZIGZAG / ORC_KEEP_UNIT_BITS.
