@@ -18,7 +18,6 @@ struct Geom {
                             // (four luma quarter-tiles of 16 MCUs, then Cb, then Cr)
     uint32_t nmx;           // 4:2:0 only: MCUs (16x16) per row = W8/16; there N = MCUs per frame,
                             // W8/H8 are multiples of 16 and a tile is 64 MCUs = 384 units of the scan
-    uint32_t nbx_mul, nbx_shift;  // b / nbx = (mulhi(b, nbx_mul) + b) >> nbx_shift for b < 2^31 (round-up reciprocal, make_geom)
     uint64_t frame_stride;  // bytes between frames = W*H*3
 };
 inline bool is420(const Geom& g) { return g.passes == 6; }
@@ -36,7 +35,6 @@ inline size_t unit_off_words(const Geom& g) { return (size_t)g.tiles * 192; }
 // Device pointers of the screened (integer-MFMA) pipeline, jpeg_screen_kernels.hip.
 struct ScreenParams {
     const uint4* afrag;     // [4 row tiles][5 digits][64 lanes] 16 int8: MFMA A fragments of the fixed-point map
-    const uint4* afrag_h;   // strict mode's first look: [4 row tiles][digit 1, 0][K half 0, 1][64 lanes] 8 f16 (integer-valued): MFMA A fragments
     const uint4* csc_frag;  // standard mode: [28 sets][64 lanes] 16 int8: MFMA A fragments of the colour conversion (jpeg_tables.h)
     const double* qconst;   // [2 channel types][64 zig-zag positions][4] = {s1, thr1, s2, thr2}
     const float* qconst_f;  // [2][16 groups of 4 positions][8] = {2^-23/Q x4, first-look threshold x4}

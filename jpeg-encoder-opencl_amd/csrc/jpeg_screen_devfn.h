@@ -8,6 +8,7 @@ namespace mi355 {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 // "does any active lane say yes": the ballot's SGPR pair compared on the scalar unit (HIP's __any goes through a
 // v_cndmask + v_cmp pair first)
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
@@ -762,107 +763,6 @@ __device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], con
                     qb[r] = (uint32_t)(z < 0.0 ? -nn : nn);
                     amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
                 }
-            }
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------
-// Strict mode's first look on the f16 matrix instruction (round 4): the fixed-point map as TWO digits of 11 bits,
-//     Lt39 = D1 2^28 + D0 2^17 + rho,   |D1| < 2^11, |D0| <= 2^10, |rho| <= 2^16   (host: upload_afrag_f16),
-// both held as INTEGER-valued f16 (exact), against the samples - 128 as f16 (exact).  v_mfma_f32_16x16x32_f16 forms
-// sum_k A[i][k] B[k][j] in fp32; every product and every partial sum of a row is an integer below 2^24 in magnitude
-// (|sum D1 p| <= 128 sum |D1| < 2^21.1 because the rows' 1-norms are <= 8; |sum D0 p| <= 64 2^10 2^7 = 2^23), hence
-// representable, hence the accumulators hi = sum D1 p and lo = sum D0 p are EXACT whatever order and internal
-// rounding the unit uses (tests/test_screen_pinning.py::test_f16_matrix_accumulators_are_exact checks the hardware
-// on adversarial and random blocks through mi355_jpeg_selftest_look).  Y = hi 2^11 + lo = (Lt39 - rho) p / 2^17, so
-//     c/Q = Y 2^-22 / Q + e,  |e| <= (E1_R + delta_R)/Q,  E1_R = 128 sum_i |rho[R][i]| 2^-39 <= 2^-10.
-// In fp32: fv = fma(hi, 2^11, lo) (one rounding), zf = fl(fv fl(2^-22/Q)): |zf - Y 2^-22/Q| <= |z| 2^-22, covered by
-// 2^-21 max|zf| in the threshold.  No integer -> float conversions and no digit recombination on the VALU: two
-// packed fmas per four positions where the int8 form needs four shift-adds, eight conversions and two packed fmas.
-// The second look is the int8 one (all five base-256 digits, fetched on demand) -- it decides as before.
-// ----------------------------------------------------------------------------
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-typedef _Float16 v2h __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int kLookFragsF16 = 4;  // [digit 1, digit 0] x [K half 0, 1]
-
-__device__ __forceinline__ void load_look_fragments_f16(const ScreenParams& sp, uint32_t lane, v4i (&A)[4][kLookFragsF16]) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int l = 0; l < kLookFragsF16; ++l) {
-            const uint4 t = sp.afrag_h[(mt * kLookFragsF16 + l) * 64 + lane];
-            A[mt][l] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
-        }
-}
-
-// 16 samples (unsigned bytes, 4 per dword, sample order) -> sample - 128 as f16: K half h = row 2 gq + h of the block.
-// 0x6400 | b is the f16 1024 + b; subtracting 1152 is exact.
-__device__ __forceinline__ void samples_to_f16(const uint32_t (&pk)[4], v4i (&Bh)[2]) {
-    const v2h kShift = {(_Float16)-1152.0f, (_Float16)-1152.0f};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t x = __builtin_amdgcn_perm(0x64646464u, pk[2 * h + (i >> 1)], (i & 1) ? 0x04030402u : 0x04010400u);
-            w[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2h, x) + kShift);
-        }
-        Bh[h] = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-    }
-}
-
-__device__ __forceinline__ void screen_quantise_f16(const v4i (&A)[kLookFragsF16], const v4i (&Bh)[2], const uint32_t (&pk)[4],
-                                                    const ScreenParams& sp, const float* __restrict__ qf /* LDS: sf[4], thr^2[4] */,
-                                                    uint32_t ct, int mt, uint32_t gq, uint32_t lane, uint32_t (&qb)[4], bool& amb) {
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    const v8h b0 = __builtin_bit_cast(v8h, Bh[0]), b1 = __builtin_bit_cast(v8h, Bh[1]);
-    v4f hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, A[0]), b0, zero, 0, 0, 0);
-    v4f lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, A[2]), b0, zero, 0, 0, 0);
-    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, A[1]), b1, hi, 0, 0, 0);
-    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, A[3]), b1, lo, 0, 0, 0);
-    const v2f k2048 = {2048.0f, 2048.0f};
-    const v2f fA = __builtin_elementwise_fma(v2f{hi[0], hi[1]}, k2048, v2f{lo[0], lo[1]});
-    const v2f fB = __builtin_elementwise_fma(v2f{hi[2], hi[3]}, k2048, v2f{lo[2], lo[3]});
-    const v2f sA = {qf[0], qf[1]}, sB = {qf[2], qf[3]};
-    const v2f M2 = {12582912.0f, 12582912.0f};
-    const v2f zA = fA * sA, zB = fB * sB;
-    const v2f aA = zA + M2, aB = zB + M2;
-    const v2f rA = aA - M2, rB = aB - M2;
-    const v2f dA = zA - rA, dB = zB - rB;  // exact: zf and its nearest integer are within 1/2 of each other
-    const v2f hA = {qf[4], qf[5]}, hB = {qf[6], qf[7]};
-    const v2f tA = __builtin_elementwise_fma(-dA, dA, hA), tB = __builtin_elementwise_fma(-dB, dB, hB);
-    float tt[4] = {tA[0], tA[1], tB[0], tB[1]};
-    if (mt == 0 && gq == 0) tt[0] = 1.0f;  // coefficient 0: overwritten by the caller, never judged here
-    qb[0] = __float_as_uint(aA[0]), qb[1] = __float_as_uint(aA[1]), qb[2] = __float_as_uint(aB[0]), qb[3] = __float_as_uint(aB[1]);
-    const float tmin = __builtin_fminf(__builtin_fminf(__builtin_fminf(tt[0], tt[1]), tt[2]), tt[3]);
-    if (wave_any(!(tmin > 0.0f))) {
-        if (lane == 0) atomicAdd(&sp.stats[0], 1ull);
-        // second look: all five base-256 digits on the int8 instruction, exact in fp64
-        const v4i B = v4i{(int)(pk[0] ^ 0x80808080u), (int)(pk[1] ^ 0x80808080u), (int)(pk[2] ^ 0x80808080u), (int)(pk[3] ^ 0x80808080u)};
-        // One digit at a time, most significant first (a rolled loop on purpose: five fragments and five accumulators live at
-        // once would set the register peak of the whole kernel for a path taken by one group in three hundred): y = y 256 + acc
-        // is exact in fp64 (|y| < 2^53).
-        double y2[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-        for (int l = kScreenLimbs - 1; l >= 0; --l) {
-            const uint4 t = sp.afrag[(mt * kScreenLimbs + l) * 64 + lane];
-            const v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w}, B, v4i{0, 0, 0, 0}, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y2[r] = y2[r] * 256.0 + (double)acc[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (!(tt[r] > 0.0f)) {
-                // {s1, thr1, s2, thr2} of this position: read from memory, the second look is rare
-                const double* qc = sp.qconst + ((size_t)ct * 64 + 16 * mt + 4 * gq + r) * 4;
-                const double z = y2[r] * qc[2];
-                const double ta = __builtin_fabs(z) + 0.5;
-                const double fr = ta - __builtin_floor(ta);
-                const int nn = (int)ta;
-                qb[r] = (uint32_t)(z < 0.0 ? -nn : nn);
-                amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
             }
         }
     }

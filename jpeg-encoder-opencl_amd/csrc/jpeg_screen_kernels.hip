@@ -56,19 +56,8 @@ constexpr uint32_t kEncWaves = 4;
 // the scan order of the luma blocks -- then Cb, Cr with one block per MCU).
 // At most 224 registers (the attribute counts in units of two on gfx90a and later: 112): two workgroups of this kernel per CU leave 64 per SIMD lane, which is what the tail kernels of the
 // part in front need to run BESIDE it (k_merge: two waves of 32 on a SIMD; above 224 batched calls lose a fifth).
-#ifndef MI355_VGPR_CAP
-#define MI355_VGPR_CAP 112
-#endif
-#ifndef MI355_LOOK_F16
-#define MI355_LOOK_F16 1
-#endif
-#if MI355_VGPR_CAP
-#define MI355_CAP_ATTR __attribute__((amdgpu_num_vgpr(MI355_VGPR_CAP)))
-#else
-#define MI355_CAP_ATTR
-#endif
 template <bool PROBE, int MODE>
-MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
+__attribute__((amdgpu_num_vgpr(112))) __global__ void __launch_bounds__(256, 2)
     k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
     constexpr bool STD = MODE != 0, S420 = MODE == 2;
     constexpr uint32_t kPasses = S420 ? 6u : 3u;
@@ -86,13 +75,7 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
     __shared__ uint32_t s_lut2[2][kLut2Words];  // (value,run) symbol tables
     __shared__ uint32_t s_dc[2][16];      // DC tables
 
-    // (the wave index through readfirstlane: the compiler cannot know that tid >> 6 is wave-uniform, and everything derived
-    // from it -- the pass coordinates, frame bases, table rows -- would be formed per lane on the VALU)
-    const uint32_t tid = threadIdx.x, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63, n = lane & 15, gq = lane >> 4;
-#ifndef MI355_OPAQUE_LANE
-#define MI355_OPAQUE_LANE 0
-#endif
-    const uint32_t lane_top = lane;
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, n = lane & 15, gq = lane >> 4;
     uint32_t* s_tbuf = s_tbuf_all[wv];
     uint32_t* s_slot = s_slot_all[wv];
     uint32_t* s_mlo = s_mask_all[wv][0];
@@ -107,12 +90,8 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
     i16a* const tb16 = reinterpret_cast<i16a*>(s_tbuf);
     // A fragments of the top three digits stay in registers; the two low digits only matter for the
     // (rare) second look and are fetched on demand.
-    // (strict: the f16 form of the first look, two digits x two K halves; standard: the int8 form, three digits)
-    constexpr bool kI8 = STD || !MI355_LOOK_F16;
-    constexpr int kFrags = kI8 ? kLookDigits : kLookFragsF16;
-    v4i A[4][kFrags];
-    if constexpr (kI8) load_look_fragments(sp, lane, A);
-    else load_look_fragments_f16(sp, lane, A);
+    v4i A[4][kLookDigits];
+    load_look_fragments(sp, lane, A);
     // quantiser divisors of coefficient 0, read once: a load per pass would sit behind everything the wave has in flight
     // (vmcnt retires in issue order), the next pass's first rows included
     const double q0_luma = sp.qd[0], q0_chroma = sp.qd[64];
@@ -166,32 +145,21 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
             else b3 = v;
         }
     };
-    // The wave's passes are p = pstart, pstart + pstep, ...; p = (frame * T + tq) * kPasses + chan with T = the tiles this
-    // wave's XCD owns per frame (all of them without the XCD map) and tile = tq * 8 + xcd (tq without it).  (frame, tq,
-    // chan) advance by a constant, with carries: no division per pass.
-    const uint32_t T = xcd_map ? tiles_x : g.tiles;
-    const uint32_t step_tq = pstep / kPasses, step_chan = pstep % kPasses;
-    struct Cursor {
-        uint32_t frame, tq, chan;
-    };
-    auto cursor_at = [&](uint32_t p) -> Cursor {  // (once per wave)
-        const uint32_t pf = T * kPasses;
-        Cursor c;
-        c.frame = p / pf;
-        const uint32_t q = p - c.frame * pf;
-        c.tq = q / kPasses;
-        c.chan = q % kPasses;
-        return c;
-    };
-    auto advance = [&](Cursor& c) {
-        c.chan += step_chan;
-        c.tq += step_tq;
-        if (c.chan >= kPasses) c.chan -= kPasses, ++c.tq;
-        while (c.tq >= T) c.tq -= T, ++c.frame;
-    };
-    auto locate = [&](const Cursor& cs) -> Pass {
+    auto locate = [&](uint32_t p) -> Pass {
         Pass ps;
-        const uint32_t frame = cs.frame, chan = cs.chan, tile = xcd_map ? cs.tq * 8u + xcd : cs.tq;
+        uint32_t frame, tile, chan;
+        if (xcd_map) {
+            const uint32_t pf = tiles_x * kPasses;
+            frame = p / pf;
+            const uint32_t q = p - frame * pf;
+            tile = (q / kPasses) * 8u + xcd;
+            chan = q % kPasses;
+        } else {
+            frame = p / per_frame;
+            const uint32_t q = p - frame * per_frame;
+            tile = q / kPasses;
+            chan = q % kPasses;
+        }
         const bool luma420 = S420 && chan < 4u;
 
         // block coordinates of this lane's four blocks (16j + n), and whether the whole tile
@@ -224,23 +192,6 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
                     ++my;
                 }
             }
-        } else if (g.fast_rows && g.nbx >= 64u && tile * 64u + 64u <= g.N) {
-            // The common case -- rows of whole blocks (W % 8 == 0), at least 64 blocks per row, a full tile: the tile's origin
-            // by one scalar division (multiply-high by the host's reciprocal), the lanes' blocks by conditional subtraction,
-            // and the tile lies inside the image iff its LAST block's row does.
-            const uint32_t t0 = tile << 6;
-            const uint32_t ty = (__umulhi(t0, g.nbx_mul) + t0) >> g.nbx_shift, tx = t0 - ty * g.nbx;
-            const uint32_t y63 = (__umulhi(t0 + 63u, g.nbx_mul) + t0 + 63u) >> g.nbx_shift;
-            uint32_t bx = tx + n, by = ty;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool wrap = bx >= g.nbx;
-                bx -= wrap ? g.nbx : 0u;
-                by += wrap ? 1u : 0u;
-                ps.set_bxy(j, bx | (by << 16));
-                bx += 16;
-            }
-            interior = y63 * 8u + 8u <= g.H;
         } else {
             uint32_t b = tile * 64 + n;
             uint32_t by = b / g.nbx, bx = b - by * g.nbx;
@@ -281,21 +232,12 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
         }
     };
     Pass cur{}, nxt{};
-    Cursor cs{0, 0, 0};
     if (pstart < pairs_total) {
-        cs = cursor_at(pstart);
-        cur = locate(cs);
+        cur = locate(pstart);
         request_first_rows(cur);
     }
     for (uint32_t p = pstart; p < pairs_total; p += pstep) {
         STAMP(7);
-#if MI355_OPAQUE_LANE
-        // Lane-derived values (row addresses, table columns, masks) are formed again in every pass: left to itself the
-        // compiler hoists dozens of them out of the loop into registers that then live for the whole kernel.
-        uint32_t lane = lane_top;
-        asm volatile("" : "+v"(lane));
-        const uint32_t n = lane & 15, gq = lane >> 4;
-#endif
         const uint32_t frame = cur.frame, tile = cur.tile, chan = cur.chan;
         // `chan` is the pass; the colour component differs from it only in 4:2:0 (passes 0..3 = luma)
         const uint32_t comp = S420 ? (chan < 4u ? 0u : chan - 3u) : chan;
@@ -325,6 +267,8 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
         const bool on_mfma = kCscMfma && fast;
         // raw RGB of unit-tile j+1 is fetched while unit-tile j is processed (that of unit-tile 0 was requested a pass ago)
         uint32_t dcsum = 0;  // sample sum of the block whose coefficient 0 this lane will form
+        // scale factors and accept thresholds of the NEXT quantiser group, requested one group ahead (see the loop below)
+        v4f qf_s = *reinterpret_cast<const v4f*>(&s_qf[ct][gq][0]), qf_h = *reinterpret_cast<const v4f*>(&s_qf[ct][gq][4]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t bx = cur.bxy(j) & 0xffffu, by = cur.bxy(j) >> 16;
@@ -379,8 +323,6 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
             // sum of the block's 64 samples (for the exact DC): 16 in this lane, then over the 4 row-pair lanes
             uint32_t ssum = 0;
             v4i B;
-            v4i Bh[2];  // strict: the same samples as f16, per K half
-            if constexpr (!kI8) samples_to_f16(pk, Bh);
             if (on_mfma) {  // signed bytes already: the sum of the unsigned samples is 16 * 128 more
                 int sg = 2048;
 #pragma unroll
@@ -394,8 +336,14 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
                 B = v4i{(int)(pk[0] ^ 0x80808080u), (int)(pk[1] ^ 0x80808080u), (int)(pk[2] ^ 0x80808080u),
                         (int)(pk[3] ^ 0x80808080u)};
             }
-            ssum += __shfl_xor(ssum, 16);
-            ssum += __shfl_xor(ssum, 32);
+            // the sum over the four row-pair lanes of a unit (lanes n, n + 16, n + 32, n + 48) without a trip through LDS:
+            // v_permlane16_swap / v_permlane32_swap exchange rows of 16 / halves of 32 between two copies of the value
+            {
+                const auto r16 = __builtin_amdgcn_permlane16_swap(ssum, ssum, false, false);
+                ssum = r16[0] + r16[1];
+                const auto r32 = __builtin_amdgcn_permlane32_swap(ssum, ssum, false, false);
+                ssum = r32[0] + r32[1];
+            }
 
             // coefficient 0 is formed exactly after this loop, by the lane (n, gq == j) for unit 16j+n
             if (gq == (uint32_t)j) dcsum = ssum;
@@ -406,8 +354,19 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 uint32_t qb[4];  // low 16 bits = quantised value
-                if constexpr (kI8) screen_quantise<STD>(A[mt], B, sp, &s_qf[ct][4 * mt + gq][0], ct, mt, gq, lane, qb, amb);
-                else screen_quantise_f16(A[mt], Bh, pk, sp, &s_qf[ct][4 * mt + gq][0], ct, mt, gq, lane, qb, amb);
+                // the scale factors and thresholds of this group were requested one group ago (they depend on the row tile only:
+                // the four sets go round); read where they are used, the two LDS reads sit two instructions in front of their
+                // first use and the wave waits out the LDS latency sixteen times per pass
+                float qfr[8];
+                {
+                    const v4f qs = qf_s, qh = qf_h;
+                    const float* nq = &s_qf[ct][4 * ((mt + 1) & 3) + gq][0];
+                    qf_s = *reinterpret_cast<const v4f*>(nq);
+                    qf_h = *reinterpret_cast<const v4f*>(nq + 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) qfr[i] = qs[i], qfr[4 + i] = qh[i];
+                }
+                screen_quantise<STD>(A[mt], B, sp, qfr, ct, mt, gq, lane, qb, amb);
                 // zig-zag positions 16mt+4gq .. +3 of unit 16j+n -> transpose buffer + non-zero bits
                 i16a* row = tb16 + (16 * mt + 4 * gq) * 64 + row_unit_off(16 * j + n);
 #pragma unroll
@@ -430,9 +389,6 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) qprev[r] = qb[r];
                 }
-#ifdef MI355_SCHED_FENCE
-                __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: without it the scheduler overlaps them up to the register limit
-#endif
             }
             atomicOr(&s_mlo[16 * j + n], (nzlo << (4 * gq)) & ~1u);
             atomicOr(&s_mhi[16 * j + n], nzhi << (4 * gq));
@@ -440,8 +396,7 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
             STAMP(6);
         }
         if (p + pstep < pairs_total) {  // wave-uniform
-            advance(cs);
-            nxt = locate(cs);
+            nxt = locate(p + pstep);
             request_first_rows(nxt);
         }
         {
@@ -511,7 +466,7 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
         // by k_dc_heads from the DCs in `meta`.  Tile sums are accumulated with one atomic per wave.
         uint32_t ubits = aclen;
         {
-            const int pred = __shfl_up(dc, 1);
+            const int pred = __builtin_amdgcn_update_dpp(0, dc, 0x138, 0xf, 0xf, false);  // wave_shr:1 -- the previous lane's DC, no trip through LDS
             auto count = [&](uint32_t, uint32_t len) { ubits += len; };
             const bool dc_ok = lane == 0 || put_dc(dc - pred, s_dc[ct], count);
             if (!dc_ok && active) atomicOr(sp.status, 1u), POISON_TILE();  // MI355_E_CATEGORY
@@ -533,11 +488,23 @@ MI355_CAP_ATTR __global__ void __launch_bounds__(256, 2)
             if (lane == 0) atomicOr(sp.status, 4u), POISON_TILE();
         } else {
             const uint32_t ncopy = oversize ? 0u : nw;
+            // the first eight words of every string are read from the slot unconditionally, back to back (the slot has 25
+            // rows: always in bounds), and only the stores are predicated: read under its predicate, each word costs a full
+            // LDS round trip in front of its store
+            uint32_t sw[8];
+#pragma unroll
+            for (uint32_t w = 0; w < 8; ++w) sw[w] = s_slot[w * 64 + lane];
 #pragma unroll
             for (uint32_t w = 0; w < 8; ++w)
-                if (w < ncopy) sp.arena[off + w] = s_slot[w * 64 + lane];
-            for (uint32_t w = 8; wave_any(w < ncopy); ++w)
-                if (w < ncopy) sp.arena[off + w] = s_slot[w * 64 + lane];
+                if (w < ncopy) sp.arena[off + w] = sw[w];
+            for (uint32_t w = 8; wave_any(w < ncopy); w += 4) {  // (24 slot rows + the dump row: rows w .. w + 3 exist for w <= 20)
+                uint32_t s4[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) s4[i] = s_slot[(w + i) * 64 + lane];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i)
+                    if (w + i < ncopy) sp.arena[off + w + i] = s4[i];
+            }
             const uint64_t again = __ballot(oversize && nw);
             if (again) {  // string longer than the LDS slot (q50: never; noise at q90: most luma units): walk again, straight to memory
                 n_rewalked += (uint32_t)__popcll(again);

@@ -24,10 +24,6 @@
 #include "jpeg_screen_tables.h"
 #include "jpeg_tables.h"
 
-#ifndef MI355_LOOK_F16
-#define MI355_LOOK_F16 1
-#endif
-
 using namespace mi355;
 
 namespace {
@@ -211,22 +207,6 @@ int ensure(T*& p, size_t& cap, size_t need, bool zero = false) {
     return MI355_OK;
 }
 
-// (strict mode's first look: see upload_afrag_f16)
-struct LookDigits {
-    int32_t d1, d0;
-    int64_t rho;
-};
-LookDigits split_look(int R, int i) {
-    int64_t v = 0;
-    for (int l = kScreenLimbs - 1; l >= 0; --l) v = v * 256 + kScreenLimb[l][R][i];
-    auto fdiv = [](int64_t a, int64_t b) { return (a >= 0 ? a : a - (b - 1)) / b; };  // floor division, b > 0
-    LookDigits d;
-    d.d1 = (int32_t)fdiv(v + (1ll << 27), 1ll << 28);
-    const int64_t r1 = v - (int64_t)d.d1 * (1ll << 28);
-    d.d0 = (int32_t)fdiv(r1 + (1ll << 16), 1ll << 17);
-    d.rho = r1 - (int64_t)d.d0 * (1ll << 17);
-    return d;
-}
 int upload_tables(mi355_jpeg_ctx* c) {
     // The copies below run on the null stream; encode calls run on the caller's (usually non-blocking)
     // streams, which do not order themselves against it in either direction.  Wait for everything in
@@ -286,29 +266,15 @@ int upload_tables(mi355_jpeg_ctx* c) {
                     const double Q = (double)(ct ? c->qchrom[zz[R]] : c->qlum[zz[R]]);
                     const auto& limb = m ? kStdLimb : kScreenLimb;
                     const double delta = kScreenEps[R] + kScreenFixErr;
-                    double e1, zmax;
-                    if (m == 0 && MI355_LOOK_F16) {
-                        // strict: the f16 first look (screen_quantise_f16): dropped part rho, kept part D1 2^11 + D0 in units of 2^-22
-                        double srho = 0, skept = 0;
-                        for (int i = 0; i < 64; ++i) {
-                            const LookDigits d = split_look(R, i);
-                            srho += std::fabs((double)d.rho);
-                            skept += std::fabs(2048.0 * d.d1 + (double)d.d0);
-                        }
-                        e1 = std::ldexp(128.0 * srho, -kScreenFracBits);
-                        zmax = std::ldexp(128.0 * skept, -22) / Q * 1.000002;
-                        qf[m][ct][grp][r] = (float)(std::ldexp(1.0, -22) / Q);
-                    } else {
-                        long s1 = 0, s0 = 0;
-                        for (int i = 0; i < 64; ++i) s1 += std::abs((int)limb[1][R][i]), s0 += std::abs((int)limb[0][R][i]);
-                        e1 = std::ldexp(128.0 * (256.0 * (double)s1 + (double)s0), -kScreenFracBits);
-                        double s3 = 0;
-                        for (int i = 0; i < 64; ++i)
-                            s3 += std::fabs(65536.0 * limb[4][R][i] + 256.0 * limb[3][R][i] + (double)limb[2][R][i]);
-                        zmax = std::ldexp(128.0 * s3, 16 - kScreenFracBits) / Q * 1.000002;
-                        qf[m][ct][grp][r] = (float)(std::ldexp(1.0, 16 - kScreenFracBits) / Q);
-                    }
-                    // |zf - (kept part) p / Q| <= |z| 2^-22 (+ 2^-18/Q for the int8 form's integer conversion): covered by 2^-21 max|zf|
+                    long s1 = 0, s0 = 0;
+                    for (int i = 0; i < 64; ++i) s1 += std::abs((int)limb[1][R][i]), s0 += std::abs((int)limb[0][R][i]);
+                    const double e1 = std::ldexp(128.0 * (256.0 * (double)s1 + (double)s0), -kScreenFracBits);
+                    // the |zf| 2^-21 term at the row's largest |zf|: |Y' 2^-23| <= 128 sum_i |top three digits of row R|
+                    double s3 = 0;
+                    for (int i = 0; i < 64; ++i)
+                        s3 += std::fabs(65536.0 * limb[4][R][i] + 256.0 * limb[3][R][i] + (double)limb[2][R][i]);
+                    const double zmax = std::ldexp(128.0 * s3, 16 - kScreenFracBits) / Q * 1.000002;
+                    qf[m][ct][grp][r] = (float)(std::ldexp(1.0, 16 - kScreenFracBits) / Q);
                     const double tau = ((e1 + std::ldexp(1.0, -18) + delta) / Q * 1.000001) * c->tau_scale + std::ldexp(1.0, -22);
                     const double thr = 0.5 - tau - std::ldexp(zmax, -21);
                     // the kernel tests d^2 < thr^2: the square, rounded DOWN to float (negative: never accepted)
@@ -373,35 +339,6 @@ int upload_afrag(mi355_jpeg_ctx* c) {
     return MI355_OK;
 }
 
-// Strict mode's first look (jpeg_screen_devfn.h, screen_quantise_f16): the 39-bit fixed-point map as two 11-bit digits
-// Lt39 = D1 2^28 + D0 2^17 + rho, D1 and D0 as integer-valued f16.  Fragment (mt, digit, K half h), lane l = (m = l & 15,
-// g = l >> 4) holds row 16 mt + m, input samples 16 g + 8 h .. + 7 (= row 2 g + h of the 8x8 block: the order in which a
-// lane of the kernel holds its samples).
-uint16_t f16_of_int(int v) {  // |v| <= 2048: exact
-    if (v == 0) return 0;
-    const uint16_t sign = v < 0 ? 0x8000u : 0u;
-    unsigned a = (unsigned)(v < 0 ? -v : v);
-    int e = 0;
-    while ((a >> (e + 1)) != 0) ++e;  // a in [2^e, 2^(e+1))
-    const unsigned mant = (a << (10 - e)) & 0x3FFu;
-    return (uint16_t)(sign | ((unsigned)(e + 15) << 10) | mant);
-}
-constexpr size_t kAfragF16Bytes = (size_t)4 * 4 * 64 * 16;
-int upload_afrag_f16(mi355_jpeg_ctx* c, size_t byte_offset) {
-    std::vector<uint16_t> h(kAfragF16Bytes / 2);
-    for (int mt = 0; mt < 4; ++mt)
-        for (int digit = 0; digit < 2; ++digit)  // fragment order: D1 h0, D1 h1, D0 h0, D0 h1
-            for (int hh = 0; hh < 2; ++hh)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int e = 0; e < 8; ++e) {
-                        const LookDigits d = split_look(16 * mt + (lane & 15), 16 * (lane >> 4) + 8 * hh + e);
-                        if (d.d1 < -2047 || d.d1 > 2047 || d.d0 < -1024 || d.d0 > 1024) return MI355_E_INTERNAL;
-                        h[((((size_t)mt * 4 + digit * 2 + hh) * 64 + lane) * 8) + e] = f16_of_int(digit == 0 ? d.d1 : d.d0);
-                    }
-    HIP_TRY(hipMemcpy((uint8_t*)c->d_afrag + byte_offset, h.data(), kAfragF16Bytes, hipMemcpyHostToDevice));
-    return MI355_OK;
-}
-
 // MFMA A fragments of standard mode's per-pixel colour conversion (jpeg_tables.h; used by the 4:4:4 kernel).  The B operand of v_mfma_i32_16x16x64_i8 is raw
 // RGB: lane (n, g) supplies 16 consecutive bytes (XOR 0x80 = x - 128) of ITS OWN rows as K chunk g, so the A matrix is
 // block diagonal -- output row 4g + r only reads K chunk g -- and lane (n, g) receives the four outputs r = 0..3 computed
@@ -454,15 +391,6 @@ int make_geom(uint32_t W, uint32_t H, uint32_t flags, const void* base, Geom* g)
     g->N = (W8 / A) * (H8 / A);  // 8x8 blocks per channel, or 16x16 MCUs in 4:2:0
     g->tiles = (g->N + 63) / 64;
     g->flags = flags;
-    {   // reciprocal of nbx: M = floor(2^(32 + s) / d) + 1 with s = ceil(log2 d); q = (mulhi(n, M - 2^32) + n) >> s is n / d
-        // for every n the sum does not overflow (n < 2^31; block indices are below 2^26)
-        const uint32_t d = g->nbx;
-        uint32_t sh = 0;
-        while ((1u << sh) < d) ++sh;
-        const unsigned __int128 M = (((unsigned __int128)1 << (32 + sh)) / d) + 1;
-        g->nbx_mul = (uint32_t)(M - ((unsigned __int128)1 << 32));
-        g->nbx_shift = sh;
-    }
     g->frame_stride = (uint64_t)W * H * 3;
     // the fast row loads use 32-bit byte offsets inside a frame (load_raw_rowpair)
     g->fast_rows = (W % 8 == 0) && (((uintptr_t)base & 7u) == 0) && ((uint64_t)W * H * 3u < (1ull << 32));
@@ -522,7 +450,6 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     const bool stdm = (g.flags & MI355_F_STANDARD) != 0;
     sp.afrag = c->d_afrag + (stdm ? kAfragBytes / sizeof(uint4) : 0);
     sp.csc_frag = c->d_afrag + 2 * kAfragBytes / sizeof(uint4);
-    sp.afrag_h = c->d_afrag + (2 * kAfragBytes + (size_t)kCscSets * 1024) / sizeof(uint4);
     sp.qconst = c->d_qconst;
     sp.qconst_f = c->d_qconst_f + (stdm ? 256 : 0);
     sp.qd = c->d_q;
@@ -894,7 +821,7 @@ static int create_body(int device_id, mi355_jpeg_ctx** out){
         hipMalloc((void**)&c->d_qzz, 128 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut, 2048 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_status, sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_afrag, 2 * kAfragBytes + (size_t)kCscSets * 1024 + kAfragF16Bytes) != hipSuccess ||
+        hipMalloc((void**)&c->d_afrag, 2 * kAfragBytes + (size_t)kCscSets * 1024) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst_f, 512 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut2, 4 * 66 * 16 * sizeof(uint32_t)) != hipSuccess ||
@@ -906,7 +833,6 @@ static int create_body(int device_id, mi355_jpeg_ctx** out){
     if (!e) e = hip_err(hipMemset(c->d_counters, 0, 64 * sizeof(uint32_t)));
     if (!e) e = upload_afrag(c);
     if (!e) e = upload_csc_frag(c);
-    if (!e) e = upload_afrag_f16(c, 2 * kAfragBytes + (size_t)kCscSets * 1024);
     if (!e) e = upload_tables(c);
     if (!e) e = hip_err(hipDeviceSynchronize());  // every fill and table copy above has landed
     if (e) {
