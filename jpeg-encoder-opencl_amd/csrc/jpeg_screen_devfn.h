@@ -437,32 +437,32 @@ static_assert((kRowSentinel + 32) * kLut2Cols + kRunNone == 65 * kLut2Cols, "exh
 constexpr uint32_t kLut2Miss = 31u;
 
 // Left-aligned 32-bit bit packer.  e = symbol bits left-aligned | length (<= 27) in bits 4..0.
-// Every put stores the word being filled (a later put to the same word overwrites it).  The packer keeps the POSITION
-// of that word in the store's own units (Store::kStep per word: an LDS byte address for StoreLds, a word index for
-// StoreGlobal), so that the store needs one clamp and no address arithmetic per symbol.
+// Every put stores the word being filled (a later put to the same word overwrites it).  State: the pending bits, the
+// TOTAL number of bits put so far (the shifts only look at its low five bits, so the count within the word is never
+// masked out), and the position of the word being filled in the store's own units (Store::at(word): an LDS byte
+// address for StoreLds, a word index for StoreGlobal) -- one shift, one shift-add and one compare per symbol for the
+// bookkeeping (round 3: add, compare, shift, and, add, and).
 template <typename Store>
 struct Packer32 {
     uint32_t acc = 0;  // pending bits, left-aligned
-    uint32_t n = 0;    // pending count, 0..31
+    uint32_t nt = 0;   // bits put so far
     uint32_t pos;      // position of the word being filled
     Store st;
-    __device__ __forceinline__ explicit Packer32(Store s) : pos(s.first()), st(s) {}
+    __device__ __forceinline__ explicit Packer32(Store s) : pos(s.at(0u)), st(s) {}
     __device__ __forceinline__ void put(uint32_t e) {
         const uint32_t ml = e & ~31u, t = e & 31u;
-        const uint32_t hi = acc | (ml >> n);
-        const uint32_t lo = __builtin_amdgcn_alignbit(ml, 0u, n);  // ml << (32-n), and 0 when n == 0
-        const uint32_t n2 = n + t;
+        const uint32_t hi = acc | (ml >> (nt & 31u));                      // (the shift instruction ignores the upper bits itself)
+        const uint32_t lo = __builtin_amdgcn_alignbit(ml, 0u, nt & 31u);   // ml << (32 - n), and 0 when n == 0
         st(pos, hi);
-        const bool adv = n2 >= 32u;
-        acc = adv ? lo : hi;
-        pos += (n2 >> 5) * Store::kStep;
-        n = n2 & 31u;
+        nt += t;
+        const uint32_t pos2 = st.at(nt >> 5);
+        acc = pos2 != pos ? lo : hi;
+        pos = pos2;
     }
     __device__ __forceinline__ void finish() { st(pos, acc); }
-    __device__ __forceinline__ void reset() { acc = 0, n = 0, pos = st.first(); }
-    __device__ __forceinline__ uint32_t done() const { return (pos - st.first()) / Store::kStep; }  // completed words
-    __device__ __forceinline__ uint32_t bits() const { return done() * 32u + n; }
-    __device__ __forceinline__ uint32_t words() const { return done() + (n ? 1u : 0u); }
+    __device__ __forceinline__ void reset() { acc = 0, nt = 0, pos = st.at(0u); }
+    __device__ __forceinline__ uint32_t bits() const { return nt; }
+    __device__ __forceinline__ uint32_t words() const { return (nt + 31u) >> 5; }
 };
 
 typedef __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
@@ -470,7 +470,11 @@ struct StoreLds {  // [word][lane]: kSlotRows words per unit are kept; later wor
     static constexpr uint32_t kStep = 256;  // LDS bytes from one word of a unit to the next (64 lanes)
     uint32_t base;                          // LDS byte address of this lane's column
     __device__ __forceinline__ explicit StoreLds(uint32_t* col) : base((uint32_t)(uintptr_t)(lds_u32_ptr)col) {}
-    __device__ __forceinline__ uint32_t first() const { return base; }
+    __device__ __forceinline__ uint32_t at(uint32_t word) const {
+        uint32_t a;  // base + word * 256 as ONE shift-add (the compiler folds the caller's nt >> 5 into shift + mask + add)
+        asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(a) : "v"(word), "v"(base));
+        return a;
+    }
     __device__ __forceinline__ void operator()(uint32_t pos, uint32_t v) const {
         const uint32_t lim = base + MI355_SLOT_ROWS * kStep;  // the dump row
         *(lds_u32_ptr)(uintptr_t)(pos < lim ? pos : lim) = v;
@@ -479,7 +483,7 @@ struct StoreLds {  // [word][lane]: kSlotRows words per unit are kept; later wor
 struct StoreGlobal {  // lane-private run of kSlotWordsFull words
     static constexpr uint32_t kStep = 1;
     uint32_t* dst;
-    __device__ __forceinline__ uint32_t first() const { return 0u; }
+    __device__ __forceinline__ uint32_t at(uint32_t word) const { return word; }
     __device__ __forceinline__ void operator()(uint32_t w, uint32_t v) const {
         dst[w < kSlotWordsFull - 1 ? w : kSlotWordsFull - 1] = v;
     }
@@ -513,7 +517,6 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {  // uniform result
 }
 
 struct WalkA {  // stage A result: position of a symbol + its value read in flight
-    uint32_t pos;
     uint32_t run;  // zeros between the previous symbol and this one
     uint32_t u;    // the coefficient as stored: 16 bits, zero-extended
 };
@@ -528,26 +531,24 @@ typedef uint16_t __attribute__((may_alias)) u16a;
 // (RLEBlockAC, utils.cpp:586-596).  Those positions -- prev + 16, prev + 32, ... below the next non-zero -- are made
 // "virtual non-zeros" before the walk: their bit is set in the walk mask, so the walk visits them like any symbol --
 // a ZERO coefficient after a run of 15, which is exactly where the symbol table keeps ZRL -- and every run it ever
-// sees is below 16.  Finding them is a short wave-uniform loop of 64-bit bit tricks: one round per ZRL of the unit
-// that has the most (none in 99 % of the luma units of noise, one or two in a third of the chroma units); one cheap
-// round when there is nothing to do.  All lanes must be active.  Returns the walk mask (bit 0 clear).
+// sees is below 16.  Returns the walk mask (bit 0 clear).
 __device__ __forceinline__ uint64_t mark_zero_runs(uint64_t mask) {
-    uint64_t x = mask | 1ull;  // position 0 counts as the start of the first run
-    for (;;) {
-        uint64_t y = x;  // bit q of y: x has a bit in [q - 15, q]
-        y |= y << 1;
-        y |= y << 2;
-        y |= y << 4;
-        y |= y << 8;
-        const uint64_t f = x & ~(y << 1) & ~1ull;  // non-zeros (real or virtual) with 16+ zeros in front
-        if (!wave_any(f != 0)) break;
-        if (f != 0) {
-            const uint32_t q = (uint32_t)__builtin_ctzll(f);
-            const uint32_t p = 63u - (uint32_t)__builtin_clzll(x & ((1ull << q) - 1ull));  // the non-zero before the run
-            x |= 1ull << (p + 16u);                                                         // < q
-        }
-    }
-    return x & ~1ull;
+    // Closed form (round 4; rounds 2-3 looped once per ZRL of the unit that has the most, with a wave-wide test per round).
+    // x: the non-zeros, position 0 counting as the start of the first run.  For a non-zero at p the reference emits ZRLs at
+    // p + 16, p + 32, p + 48 as far as they lie in front of the NEXT non-zero, i.e. candidate c = p + 16 k is one iff x has
+    // no bit in (p, c].  y = x smeared upwards by 15: bit q of y says "x has a bit in [q - 15, q]", so (p, p + 16] is
+    // clear iff bit c of y is, (p, p + 32] iff bits c and c - 16 of y are, and so on.  Zeros after the unit's LAST
+    // non-zero end in EOB, not in ZRLs: candidates at or above it are dropped.
+    const uint64_t x = mask | 1ull;
+    uint64_t y = x;
+    y |= y << 1;
+    y |= y << 2;
+    y |= y << 4;
+    y |= y << 8;
+    const uint64_t n1 = ~y, n2 = n1 & ~(y << 16), n3 = n2 & ~(y << 32);
+    const uint64_t z = ((x << 16) & n1) | ((x << 32) & n2) | ((x << 48) & n3);
+    const uint64_t below_last = (1ull << (63u - (uint32_t)__builtin_clzll(x))) - 1ull;  // x != 0
+    return (mask | (z & below_last)) & ~1ull;
 }
 
 // row: this lane's unit in the [position][unit] row buffer (row[pos * 64] = coefficient at zig-zag
@@ -582,11 +583,11 @@ __device__ __forceinline__ void walk_loop(const u16a* rowu, uint64_t mask, const
         asm("v_ffbl_b32 %0, %1" : "=v"(t) : "v"((uint32_t)m));
         t = t < kRunNone ? t : kRunNone;  // zeros in front of the symbol (< 16); kRunNone = none left
         const uint32_t nx = prev + t + 1u;
-        a.pos = nx < 64u ? nx : 64u;
+        const uint32_t pos = nx < 64u ? nx : 64u;
         a.run = t;
         m >>= (t + 1u) & 63u;
-        prev = a.pos;
-        a.u = rowu[a.pos * 64u];
+        prev = pos;
+        a.u = rowu[pos * 64u];
         return a;
     };
     auto stageB = [&](const WalkA& a) -> WalkB {
@@ -594,7 +595,9 @@ __device__ __forceinline__ void walk_loop(const u16a* rowu, uint64_t mask, const
         b.u = a.u;
         b.r = a.run;
         // table row = clamp(v, -32, 32) + 32 without sign extension: (u + 32) mod 2^16 is v + 32 for v in [-32, 32] and
-        // something above 64 for every other value, which the minimum sends to row 64 (= +32: an all-zero row)
+        // something above 64 for every other value, which the minimum sends to row 64 (= +32: kLut2Miss in every column).
+        // (A sign-extending read + three-input median + signed multiply-add is one instruction less and was NOT faster:
+        // 253.0 against 254.7 Gpixel/s over three 100-step rounds, gpurun r4q.)
         const uint16_t t = (uint16_t)(a.u + 32u);
         const uint32_t trow = t < 64 ? t : 64;
         // LDS byte address by hand -- one shift-add, one 24-bit multiply-add (the compiler prefers three instructions)

@@ -410,6 +410,9 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ void __launch_bounds__(256, 2)
                 const int n0 = (int)((a0 + 4u * Q0) / (8u * Q0));
                 q0 = sl < 0 ? -n0 : n0;
             } else {
+                // (fp64, ~30 double-rate instructions per lane and pass -- and still faster than reading the 16321 possible
+                // results from a table in memory: 251.8 against 256.9 Gpixel/s with the table, even with its request issued
+                // in front of the next pass's rows, gpurun r4r / r4s)
                 const double c0 = (double)((int)dcsum - 8192) * kScale00;
                 q0 = (int)__builtin_round(c0 / (ct ? q0_chroma : q0_luma));
             }

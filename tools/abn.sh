@@ -6,9 +6,9 @@ set -e
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"
 P=$GRAFT_REPO_ROOT/jpeg-encoder-opencl_amd
-for r in 1 2; do
+for r in $(seq 1 ${ABN_ROUNDS:-2}); do
   for L in "$@"; do
-    MI355_JPEG_LIB=$P/$L python bench.py --quick --no-cpu-baseline > "$OUT/$L.$r.json" 2> "$OUT/$L.$r.err"
+    MI355_JPEG_LIB=$P/$L python bench.py --quick --no-cpu-baseline --steps ${ABN_STEPS:-20} > "$OUT/$L.$r.json" 2> "$OUT/$L.$r.err"
     python - "$OUT/$L.$r.json" "$L" <<'PY'
 import json,sys
 j=json.load(open(sys.argv[1]))
@@ -16,6 +16,7 @@ print("%-28s value %.1f Gpx/s  ms/frame %.5f  kernel ms/frame %.5f"%(sys.argv[2]
 PY
   done
 done
+[ -n "$ABN_NO_CFG" ] && exit 0
 for L in "$@"; do
   echo "$L"; MI355_JPEG_LIB=$P/$L python tools/config_bench.py 2>/dev/null | grep "^{" | python -c "import sys,json; [print('  ', j['case'], j['Gpixel_per_s'], j['stage_ms']) for j in map(json.loads, sys.stdin)]"
 done
