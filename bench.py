@@ -57,7 +57,7 @@ GOLDEN_SEED1_BITS = 38227880
 GOLDEN_SEED1_SHA = "6a4a20a6412d6e3bfd878e09875156170ff80a74d7c10c04b52a425e7dbcf009"
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ALG_FP64_OPS_PER_UNIT = 12416   # 64*64*3 + 64 + 64 per (block, channel)
-DTYPE = "f16/i8-mfma + fp32 screen, f64 arbiter (results bit-identical to the reference's f64 path)"
+DTYPE = "i8-mfma + fp32 screen, f64 arbiter (results bit-identical to the reference's f64 path)"
 GOLDEN_16K = (3938207090, "22a3a76e3a7ceb82d483d31262f3b67bce5668bed019bcca7f457094bb64fe54")  # 16384^2 LCG seed 1, q90, no averaging
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box helper (round 4): the round's evidence in one call.  usage: tools/r4_final.sh <tag> [steps...]
-# steps: test bench prof pmc cfgpmc overlap   (default: all).  Steps are joined with && semantics (set -e).
+# steps: test bench prof pmc cfgpmc overlap stamps   (default: all but stamps, which needs libmi355jpeg_stamps.so = a `make STAMPS=1` build).  Steps are joined with && semantics (set -e).
 set -e -o pipefail
 TAG=$1; shift
 STEPS=${@:-test bench prof pmc cfgpmc overlap}
@@ -32,6 +32,8 @@ for STEP in $STEPS; do
     overlap)
       rocprofv3 --kernel-trace --output-format csv -d "$OUT/overlap" -- python3 tools/overlap_probe.py > "$OUT/overlap.log" 2>&1 || { tail -20 "$OUT/overlap.log"; exit 1; }
       python3 tools/overlap_summary.py "$OUT/overlap" "$OUT/overlap_summary.json" ;;
+    stamps)
+      MI355_JPEG_LIB=$GRAFT_REPO_ROOT/jpeg-encoder-opencl_amd/libmi355jpeg_stamps.so python3 tools/stamps.py > "$OUT/stamps.txt" 2>&1 || { tail -20 "$OUT/stamps.txt"; exit 1; }; tail -8 "$OUT/stamps.txt" ;;
     *) echo "unknown step $STEP"; exit 2 ;;
   esac
 done
