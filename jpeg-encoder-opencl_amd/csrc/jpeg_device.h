@@ -42,7 +42,8 @@ struct ScreenParams {
     const uint32_t* qnat_zz; // [2][64] quantiser divisors as integers, ZIG-ZAG order (standard mode's exact decision)
     const uint32_t* lut;    // [4][256] Huffman LUTs (code << 5 | len)
     const uint32_t* lut2;   // [2 channel types][66 rows: value + 32][16 columns: run] whole AC symbols, left-aligned | length
-    uint2* meta;            // [frame][tile][chan][64] {arena word offset, aclen << 16 | (uint16)dc}
+    uint32_t* meta;         // [frame][tile][pass][64] aclen << 16 | (uint16)dc
+    uint32_t* pass_off;     // [frame][tile][pass] arena word offset of the pass's first string (the others follow in lane order)
     uint32_t* arena;        // AC bit strings, one word-aligned blob per unit
     uint32_t arena_words;   // = grid * region_words + overflow pool
     uint32_t region_words;  // private region of each persistent wave (bump-allocated without atomics)
@@ -63,7 +64,7 @@ uint32_t screen_grid(const Geom& g, uint32_t n_frames, uint32_t max_waves);
 hipError_t launch_screen_encode(const Geom& g, uint32_t n_frames, const uint8_t* rgb, const ScreenParams& sp,
                                 bool probe, uint32_t grid_waves, hipStream_t s);
 hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams& sp, hipStream_t s);
-hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,
+hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint32_t* meta, const uint32_t* pass_off, const uint32_t* arena,
                         const uint32_t* lut, const uint64_t* tile_off,
                         uint8_t* out, uint64_t out_stride, const uint64_t* frame_bits /* ~0: the frame is skipped */,
                         uint32_t lds_words_limit, hipStream_t s);

@@ -369,7 +369,7 @@ __device__ __forceinline__ void std_rowpair_mfma(const RawChunk (&X)[4], const v
 // ----------------------------------------------------------------------------
 // (ScreenParams is declared in jpeg_device.h)
 
-__device__ __forceinline__ int meta_dc(uint32_t y) { return (int)(int16_t)(y & 0xffffu); }
+__device__ __forceinline__ int meta_dc(uint32_t w) { return (int)(int16_t)(w & 0xffffu); }
 
 // Arena allocation for one wave.  Every persistent wave owns a private region and bumps a
 // private pointer (no atomics: a returning atomic on one address saturates at ~88 per

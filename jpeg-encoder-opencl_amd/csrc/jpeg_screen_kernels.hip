@@ -518,7 +518,9 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ void __launch_bounds__(256, 2)
                 }
             }
         }
-        sp.meta[us_base + lane] = make_uint2(off, active ? ((aclen << 16) | ((uint32_t)dc & 0xffffu)) : 0u);
+        // 4 bytes per unit: the arena offset is not stored, k_merge forms it from the pass's base and a scan of the lengths
+        sp.meta[us_base + lane] = active ? ((aclen << 16) | ((uint32_t)dc & 0xffffu)) : 0u;
+        if (lane == 0) sp.pass_off[us_base >> 6] = base;
         __builtin_amdgcn_wave_barrier();
         STAMP(4);
         cur = nxt;
@@ -563,12 +565,12 @@ __global__ void __launch_bounds__(64)
             // a quarter-tile past the last MCU has no units at all
             luma = c < 4;
             if (luma && (ft % g.tiles) * 64 + 16 * c >= g.N) continue;
-            if (luma && c > 0) pred = meta_dc(sp.meta[u0 - 64 + 63].y);
-            else if (tile > 0) pred = meta_dc(sp.meta[u0 - 6 * 64 + (luma ? 3 * 64 : 0) + 63].y);
+            if (luma && c > 0) pred = meta_dc(sp.meta[u0 - 64 + 63]);
+            else if (tile > 0) pred = meta_dc(sp.meta[u0 - 6 * 64 + (luma ? 3 * 64 : 0) + 63]);
         } else if (tile > 0) {
-            pred = meta_dc(sp.meta[u0 - 192 + 63].y);
+            pred = meta_dc(sp.meta[u0 - 192 + 63]);
         }
-        const int dc = meta_dc(sp.meta[u0].y);
+        const int dc = meta_dc(sp.meta[u0]);
         uint32_t len = 0;
         auto count = [&](uint32_t, uint32_t l) { len += l; };
         if (!put_dc(dc - pred, s_dcf[luma ? 0 : 1], count)) atomicOr(sp.status, 1u), POISON_FT();  // MI355_E_CATEGORY
@@ -579,12 +581,12 @@ __global__ void __launch_bounds__(64)
 // ----------------------------------------------------------------------------
 // DC predictor of a unit from `meta`: the previous lane, or the last block of the previous tile.
 // ----------------------------------------------------------------------------
-__device__ __forceinline__ int meta_pred(const uint2* __restrict__ meta, size_t frame_tile0, uint32_t tile,
+__device__ __forceinline__ int meta_pred(const uint32_t* __restrict__ meta, size_t frame_tile0, uint32_t tile,
                                          uint32_t chan, uint32_t lane, int own_dc) {
     int prev = __shfl_up(own_dc, 1);
     if (lane == 0) {
         prev = 0;
-        if (tile > 0) prev = meta_dc(meta[((frame_tile0 + tile - 1) * 3 + chan) * 64 + 63].y);
+        if (tile > 0) prev = meta_dc(meta[((frame_tile0 + tile - 1) * 3 + chan) * 64 + 63]);
     }
     return prev;
 }
@@ -597,7 +599,7 @@ __device__ __forceinline__ int meta_pred(const uint2* __restrict__ meta, size_t 
 // encode kernel stored as pass (4 mcu + k) / 64, lane (4 mcu + k) % 64; k = 4, 5: Cb, Cr).
 template <bool S420>
 __global__ void __launch_bounds__(S420 ? 384 : 192)
-    k_merge(Geom g, const uint2* __restrict__ meta, const uint32_t* __restrict__ arena,
+    k_merge(Geom g, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ pass_off, const uint32_t* __restrict__ arena,
             const uint32_t* __restrict__ lut, const uint64_t* __restrict__ tile_off,
             uint8_t* __restrict__ out, uint64_t out_stride, const uint64_t* __restrict__ frame_bits,
             uint32_t lds_words_limit) {
@@ -638,11 +640,22 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
     // this unit: DC, AC length, arena offset; the first words of its AC string are fetched now
     bool active, chroma, tile_end;  // tile_end: the last unit of the tile's scan
     uint32_t spos;  // position of the unit in the tile's scan
-    uint2 m;
+    uint32_t mw, moff;  // the unit's metadata word (aclen << 16 | dc) and the arena offset of its AC string
     int dc, pred;
+    // Arena offsets are not stored per unit: a pass's strings lie back to back from the pass's base in lane order, so a
+    // unit's offset is the base plus the words of the lanes in front of it -- one wave scan over the pass's 64 metadata words.
+    auto words_of = [](uint32_t w) {
+        const uint32_t nwz = ((w >> 16) + 31u) >> 5;
+        return nwz > kSlotRows ? kSlotWordsFull : nwz;  // oversized strings own a full-size run (k_screen_encode)
+    };
     if constexpr (S420) {
         const uint32_t mcu = tid / 6, k = tid - mcu * 6;
         const size_t t0 = (ft0 + tile) * 6 * 64;
+        {   // wave w = pass w of the tile: offsets in pass order through s_bits, picked up in scan order below
+            const uint32_t need = words_of(meta[t0 + tid]);
+            s_bits[tid] = pass_off[(ft0 + tile) * 6 + (tid >> 6)] + wave_incl_scan(need, lane) - need;
+            __syncthreads();
+        }
         spos = tid;
         chroma = k >= 4;
         active = tile * 64 + mcu < g.N;
@@ -650,30 +663,34 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
         pred = 0;
         if (!chroma) {
             const uint32_t L = 4 * mcu + k;  // pass L >> 6, lane L & 63: slot t0 + L
-            m = meta[t0 + L];
-            if (L > 0) pred = meta_dc(meta[t0 + L - 1].y);
-            else if (ptile > 0) pred = meta_dc(meta[t0 - 6 * 64 + 3 * 64 + 63].y);
+            mw = meta[t0 + L];
+            moff = s_bits[L];
+            if (L > 0) pred = meta_dc(meta[t0 + L - 1]);
+            else if (ptile > 0) pred = meta_dc(meta[t0 - 6 * 64 + 3 * 64 + 63]);
         } else {
             const size_t slot = t0 + (size_t)k * 64 + mcu;
-            m = meta[slot];
-            if (mcu > 0) pred = meta_dc(meta[slot - 1].y);
-            else if (ptile > 0) pred = meta_dc(meta[slot - 6 * 64 + 63].y);
+            mw = meta[slot];
+            moff = s_bits[k * 64 + mcu];
+            if (mcu > 0) pred = meta_dc(meta[slot - 1]);
+            else if (ptile > 0) pred = meta_dc(meta[slot - 6 * 64 + 63]);
         }
-        dc = meta_dc(m.y);
+        dc = meta_dc(mw);
     } else {
         spos = lane * 3 + chan;
         chroma = chan != 0;
         active = tile * 64 + lane < g.N;
         tile_end = lane == last_blk && chan == 2;
-        m = meta[((ft0 + tile) * 3 + chan) * 64 + lane];
-        dc = meta_dc(m.y);
+        mw = meta[((ft0 + tile) * 3 + chan) * 64 + lane];
+        const uint32_t need = words_of(mw);
+        moff = pass_off[(ft0 + tile) * 3 + chan] + wave_incl_scan(need, lane) - need;
+        dc = meta_dc(mw);
         pred = meta_pred(meta, ft0, ptile, chan, lane, dc);
         if (restart && lane == 0) pred = 0;
     }
-    const uint32_t aclen = active ? (m.y >> 16) : 0u;
+    const uint32_t aclen = active ? (mw >> 16) : 0u;
     uint32_t pre[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pre[i] = (uint32_t)i * 32u < aclen ? arena[m.x + i] : 0u;
+    for (int i = 0; i < 4; ++i) pre[i] = (uint32_t)i * 32u < aclen ? arena[moff + i] : 0u;
     __syncthreads();
     // tile-local exclusive offsets in scan order
     uint32_t dcl = 0;
@@ -696,7 +713,9 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
     }
     __syncthreads();
     if (active) {
-        const uint64_t pos = (start & 31) + s_bits[spos];
+        const uint32_t pos = (uint32_t)(start & 31) + s_bits[spos];  // bits from the first word of the tile: below 2^21
+        // restart intervals end on a byte boundary, filled with 1s (their start is aligned)
+        const uint32_t fill = restart && tile_end ? (8u - ((pos + dcl + aclen) & 7u)) & 7u : 0u;
         auto body = [&](auto& bw) {
             auto put = [&](uint32_t code, uint32_t len) { bw.put(code, len); };
             put_dc(dc - pred, s_dc[chroma ? 1 : 0], put);
@@ -708,18 +727,15 @@ __global__ void __launch_bounds__(S420 ? 384 : 192)
                 }
             }
             for (uint32_t done = 128; done < aclen; done += 32) {
-                uint32_t w = arena[m.x + (done >> 5)];
+                uint32_t w = arena[moff + (done >> 5)];
                 uint32_t len = aclen - done < 32u ? aclen - done : 32u;
                 bw.put(w >> (32u - len), len);
             }
-            if (restart && tile_end) {  // the interval ends on a byte boundary, filled with 1s (its start is aligned)
-                const uint32_t fill = (8u - (uint32_t)((pos + dcl + aclen) & 7u)) & 7u;
-                if (fill) bw.put((1u << fill) - 1u, fill);
-            }
+            if (fill) bw.put((1u << fill) - 1u, fill);
             bw.flush();
         };
         if (use_lds) {
-            BitWriterLds bw{s_words, 0, (uint32_t)(pos & 31), (uint32_t)(pos >> 5)};
+            BitWriterLds bw{s_words, 0, pos & 31, pos >> 5};
             body(bw);
         } else {
             BitWriterGlobal bw{outw, 0, (uint32_t)(pos & 31), w0 + (pos >> 5)};
@@ -777,16 +793,16 @@ hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams&
     hipLaunchKernelGGL(k_dc_heads, dim3(head_waves), dim3(64), 0, s, g, n_frames, sp);
     return hipGetLastError();
 }
-hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint2* meta, const uint32_t* arena,
+hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint32_t* meta, const uint32_t* pass_off, const uint32_t* arena,
                         const uint32_t* lut, const uint64_t* tile_off,
                         uint8_t* out, uint64_t out_stride, const uint64_t* frame_bits, uint32_t lds_words_limit,
                         hipStream_t s) {
     if (lds_words_limit > kEmitLdsWords) lds_words_limit = kEmitLdsWords;
     if (is420(g))
-        hipLaunchKernelGGL(k_merge<true>, dim3(g.tiles, n_frames), dim3(384), 0, s, g, meta, arena, lut,
+        hipLaunchKernelGGL(k_merge<true>, dim3(g.tiles, n_frames), dim3(384), 0, s, g, meta, pass_off, arena, lut,
                            tile_off, out, out_stride, frame_bits, lds_words_limit);
     else
-        hipLaunchKernelGGL(k_merge<false>, dim3(g.tiles, n_frames), dim3(192), 0, s, g, meta, arena, lut,
+        hipLaunchKernelGGL(k_merge<false>, dim3(g.tiles, n_frames), dim3(192), 0, s, g, meta, pass_off, arena, lut,
                            tile_off, out, out_stride, frame_bits, lds_words_limit);
     return hipGetLastError();
 }

@@ -159,7 +159,7 @@ struct mi355_jpeg_ctx {
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
     uint8_t* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // scratch of the stage-by-stage entry points
     size_t stage_cap[4] = {0, 0, 0, 0};
-    uint2* d_meta = nullptr;
+    uint32_t* d_meta = nullptr;  // per workspace set: one word per unit, then one per pass (meta_words)
     size_t meta_cap = 0;
     uint32_t* d_arena = nullptr;
     size_t arena_cap = 0;           // words
@@ -406,6 +406,11 @@ int ensure_workspace(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames) {
     return MI355_OK;
 }
 
+// Per-unit metadata of the screened pipeline, in words, for n_frames frames: one word per unit slot, then one per pass
+// (the arena offset of the pass's first string).
+inline size_t meta_slots(const Geom& g, uint32_t n_frames) { return (size_t)g.tiles * g.passes * 64 * n_frames; }
+inline size_t meta_words(const Geom& g, uint32_t n_frames) { return meta_slots(g, n_frames) / 64 * 65; }
+
 constexpr size_t kMaxEventSets = 1u << 16;
 constexpr unsigned long kEmitWordsMax = 4096;  // kEmitLdsWords (jpeg_devfn.h): the bit-assembly window of k_emit / k_merge
 
@@ -413,8 +418,7 @@ constexpr unsigned long kEmitWordsMax = 4096;  // kEmitLdsWords (jpeg_devfn.h): 
 // workspace of the screened pipeline; arena_words: capacity for the AC blobs
 int ensure_screen_workspace(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, size_t arena_words) {
     int e;
-    size_t slots = (size_t)g.tiles * g.passes * 64 * n_frames;
-    if ((e = ensure(c->d_meta, c->meta_cap, slots))) return e;
+    if ((e = ensure(c->d_meta, c->meta_cap, meta_words(g, n_frames)))) return e;
     if ((e = ensure(c->d_arena, c->arena_cap, arena_words))) return e;
     return MI355_OK;
 }
@@ -457,6 +461,7 @@ ScreenParams screen_params(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, 
     sp.lut = c->d_lut + (stdm ? 1024 : 0);
     sp.lut2 = c->d_lut2 + (stdm ? 2 * 66 * 16 : 0);
     sp.meta = c->d_meta;
+    sp.pass_off = c->d_meta + meta_slots(g, n_frames);
     sp.arena = c->d_arena;
     sp.arena_words = (uint32_t)(arena_words > 0xFFFFFFFFull ? 0xFFFFFFFFull : arena_words);
     sp.counters = c->d_counters;
@@ -546,6 +551,7 @@ struct BatchPart {
 ScreenParams part_params(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p, size_t set_meta, size_t set_arena) {
     ScreenParams sp = screen_params(c, g, p.nf, p.plan, nullptr);
     sp.meta = c->d_meta + (size_t)p.set * set_meta;
+    sp.pass_off = sp.meta + set_meta / 65 * 64;  // behind the unit words of the set's largest part
     sp.arena = c->d_arena + (size_t)p.set * set_arena;
     sp.counters = c->d_counters + p.counter;
     sp.tile_bits = c->d_tile_bits + (size_t)p.f0 * g.tiles;
@@ -561,7 +567,7 @@ int launch_tails(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p, const Scr
                              true, scan_chunks(g) ? c->d_tile_off + ((size_t)g.tiles + 1) * batch_frames + (size_t)p.f0 * scan_chunks(g) : nullptr,
                              true, s));
     if (rec) record(c, 3, s);
-    HIP_TRY(launch_merge(g, p.nf, sp.meta, sp.arena, sp.lut, c->d_tile_off + (size_t)p.f0 * (g.tiles + 1),
+    HIP_TRY(launch_merge(g, p.nf, sp.meta, sp.pass_off, sp.arena, sp.lut, c->d_tile_off + (size_t)p.f0 * (g.tiles + 1),
                          d_out + (size_t)p.f0 * out_stride, out_stride, d_bits + p.f0, c->emit_lds_words, s));
     if (rec) record(c, 4, s);
     return MI355_OK;
@@ -576,7 +582,7 @@ int launch_tails(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p, const Scr
 //
 // Workspace (device memory the library allocates; grown on demand, never shrunk): TWO sets of {per-unit metadata,
 // string arena}, each sized for ONE part, whatever the batch -- parts alternate between them.  Per frame of a part:
-// 8 bytes per unit of metadata, and an arena of 2 x min(9/16 x out_stride + 4 x units, 216 x units) + 0.25 MiB bytes
+// 4 bytes per unit (+ 4 per pass) of metadata, and an arena of 2 x min(9/16 x out_stride + 4 x units, 216 x units) + 0.25 MiB bytes
 // (units = blocks x 3; 216 bytes = the longest possible AC string; the factor 2 = every wave's private region + an
 // overflow pool that could hold everything).  A part's arena offsets are 32-bit words relative to the part, so the
 // size of a batch is not limited by them; parts shrink where a frame is so large that 16 of them would not fit.
@@ -609,7 +615,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     }
     const ArenaPlan big = plan_arena(c, g, max_nf, (size_t)max_nf * frame_words, (size_t)max_nf * by_units);
     const size_t set_arena = (big.total_words + 63) & ~(size_t)63;
-    const size_t set_meta = (size_t)g.tiles * g.passes * 64 * max_nf;
+    const size_t set_meta = meta_words(g, max_nf);
     // Sets of {metadata, arena}: one per part while they fit a budget (a quarter of the free device memory, at most
     // 32 GB), otherwise as many as fit (at least 2) and part i reuses the set of part i - nsets once that part's tail
     // kernels are done.  (Reuse costs: the wait for the side stream between two block-encode launches keeps them from
@@ -618,9 +624,9 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     if (nparts > 2) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0, (void)hipGetLastError();
-        free_b += c->meta_cap * sizeof(uint2) + c->arena_cap * sizeof(uint32_t);  // what this context holds already counts as free
+        free_b += c->meta_cap * sizeof(uint32_t) + c->arena_cap * sizeof(uint32_t);  // what this context holds already counts as free
         size_t budget = free_b / 4 < ((size_t)32 << 30) ? free_b / 4 : ((size_t)32 << 30);
-        const size_t set_bytes = set_meta * sizeof(uint2) + set_arena * sizeof(uint32_t);
+        const size_t set_bytes = (set_meta + set_arena) * sizeof(uint32_t);
         const size_t fit = set_bytes ? budget / set_bytes : nparts;
         nsets = (uint32_t)(fit < 2 ? 2 : (fit < nparts ? fit : nparts));
         if (c->max_sets && nsets > c->max_sets) nsets = c->max_sets;  // tests

@@ -1,0 +1,62 @@
+"""The co-residency budget of the built kernels, read from the code objects inside libmi355jpeg.so.
+
+Batched calls run a part's tail kernels under the next part's block-encode kernel.  That only works while, on every CU,
+two workgroups of k_screen_encode leave room for a workgroup of k_merge: LDS in 1280-byte granules within 160 KiB, and on
+every SIMD two encode waves plus two k_merge waves within the 512 registers of the unified file (8-register granules).
+Measured four times by now (rounds 2-4, last: gpurun r4w -- encode at 218 registers beside k_merge at 33: 187 instead of
+256 Gpixel/s): one register or one LDS granule over the line costs a fifth to a quarter of the headline, and nothing but
+the bench shows it.  This test does, on CPU, from the build."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(ROOT, "jpeg-encoder-opencl_amd", "libmi355jpeg.so")
+
+
+def kernel_table(tmp_path):
+    """{mangled name: {vgpr, lds, scratch}} of every gfx950 kernel in the library."""
+    lib = shutil.copy(LIB, tmp_path / "lib.so")  # llvm-objdump writes the bundles next to its input
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    table = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if not f.endswith("gfx950"):
+            continue
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", str(tmp_path / f)], check=True,
+                               capture_output=True, text=True).stdout
+        for blk in notes.split("  - .agpr_count:")[1:]:
+            def field(k):
+                return re.search(r"\.%s:\s+(\S+)" % k, blk).group(1)
+            table[field("name")] = dict(vgpr=int(field("vgpr_count")), lds=int(field("group_segment_fixed_size")),
+                                        scratch=int(field("private_segment_fixed_size")))
+    return table
+
+
+def up(x, g):
+    return (x + g - 1) // g * g
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="no ROCm LLVM tools")
+def test_tail_kernels_fit_beside_the_block_encode(tmp_path):
+    assert os.path.exists(LIB), "libmi355jpeg.so not built"
+    t = kernel_table(tmp_path)
+    enc = {k: v for k, v in t.items() if "k_screen_encodeILb0E" in k}   # the shipped (non-probe) forms: strict, 4:4:4, 4:2:0
+    merge = {k: v for k, v in t.items() if "k_mergeIL" in k}
+    assert len(enc) == 3 and len(merge) == 2, sorted(t)
+    for k, v in {**enc, **merge}.items():
+        assert v["scratch"] == 0, (k, v)  # no spills on the hot path
+    for ek, e in enc.items():
+        s420 = "ILb0ELi2E" in ek
+        (mk, m), = [(k, v) for k, v in merge.items() if ("ILb1E" in k) == s420]
+        lds = 2 * up(e["lds"], 1280) + up(m["lds"], 1280)
+        regs = 2 * up(e["vgpr"], 8) + 2 * up(m["vgpr"], 8)
+        assert lds <= 160 * 1024, (ek, mk, e, m, lds)
+        assert regs <= 512, (ek, mk, e, m, regs)
+    # the small tail kernels of every frame
+    heads = [v for k, v in t.items() if "k_dc_heads" in k]
+    assert heads and all(v["vgpr"] <= 32 and v["lds"] <= 1280 for v in heads)
