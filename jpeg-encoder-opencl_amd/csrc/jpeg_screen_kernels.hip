@@ -65,7 +65,9 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ void __launch_bounds__(256, 2)
     // scheme for its chroma passes was built and measured at -1.5 % (profiles/r03_f_*) -- a matrix
     // instruction costs the issuing wave what 2.5 plain VALU instructions cost, the fixed-point form needs only four of
     // those per pixel, and the fragments' registers push the kernel to the limit beyond which the tail kernels stop
-    // running beside it.
+    // running beside it.  Strict mode does not either (round 4, gpurun r4cs-r4cu): the reference's integer numerators on
+    // the matrix units are bit-exact and 9 % SLOWER -- of the four vector instructions a pixel saves, the shift-add that joins
+    // the two digits and the x ^ 0x80 of the operand bytes take back almost two, and the matrix results arrive late.
     constexpr bool kCscMfma = MODE == 1;
     __shared__ uint32_t s_tbuf_all[kEncWaves][kRowWords];          // zig-zag rows, int16 [position][unit] (jpeg_screen_devfn.h)
     __shared__ alignas(16) uint32_t s_slot_all[kEncWaves][(kSlotRows + 1) * 64];  // AC strings [word][lane] + dump row
@@ -597,8 +599,13 @@ __device__ __forceinline__ int meta_pred(const uint32_t* __restrict__ meta, size
 // S420: the tile is 64 MCUs = 384 units; thread t = 6 * mcu + k is the unit at position t of the
 // tile's scan (k < 4: luma block k of the MCU = unit 4 mcu + k of the tile's 256 luma units, which the
 // encode kernel stored as pass (4 mcu + k) / 64, lane (4 mcu + k) % 64; k = 4, 5: Cb, Cr).
+// Launch bounds of 256 for the 192-thread form on purpose: for a three-wave workgroup with this much LDS the compiler
+// works out that at most seven waves fit a SIMD and then RAISES the kernel's register allocation to the most seven waves
+// allow -- 72 instead of the 32 it uses (.amdhsa_next_free_vgpr 65) -- and with 72 a k_merge wave only fits beside two
+// k_screen_encode waves of at most 216 registers (found in round 4 when the encode kernel went to 221 and batched calls
+// lost a quarter; tests/test_kernel_budget.py reads the allocation from the kernel descriptors now).
 template <bool S420>
-__global__ void __launch_bounds__(S420 ? 384 : 192)
+__global__ void __launch_bounds__(S420 ? 384 : 256)
     k_merge(Geom g, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ pass_off, const uint32_t* __restrict__ arena,
             const uint32_t* __restrict__ lut, const uint64_t* __restrict__ tile_off,
             uint8_t* __restrict__ out, uint64_t out_stride, const uint64_t* __restrict__ frame_bits,
