@@ -205,8 +205,13 @@ def other_configs_leg(jpeg, enc, torch, dev, stream):
             "Huffman prefix-scan throughput (BASELINE)")
         run("configs[4]: one 16384x16384 LCG frame, q90, no chroma averaging, strict", 16384, 16384, 1, 90, 0, lcg(1),
             {"n_bits": GOLDEN_16K[0], "sha_ascii": GOLDEN_16K[1], "cap": 520 << 20, "what": "SURVEY Appendix B (reference build): 3 938 207 090 bits, 22a3a76e..."},
-            4, "DCT/quant HBM-roofline stress (BASELINE): 14.7 bit/px, most luma strings exceed their 24-word slot in LDS and are "
-               "coded a second time straight into device memory (strings_walked_twice_per_unit)")
+            4, "DCT/quant HBM-roofline stress (BASELINE): 14.7 bit/px; values beyond the whole-symbol table in nearly every pass "
+               "(passes_in_general_walk_loop), no string beyond its 24-word LDS slot (strings_walked_twice_per_unit)")
+        c = golden_case("lcg_3840x2160_s1_q50_cds")
+        run("the headline workload at 100 frames per call: parts of unequal size (16 and 17 frames)", W, H, 100, 50, jpeg.F_DEFAULT, lcg(1),
+            {"n_bits": c["n_bits"], "sha_ascii": c["sha256_ascii_bits"], "cap": 8 << 20, "what": "tests/golden/cases.json lcg_3840x2160_s1_q50_cds (reference build)"},
+            6, "a batch that does not divide evenly: a part's merge can outlast the block encode it runs beside, and until round 4 "
+               "(one k_merge workgroup per CU) the next launch's persistent workgroups then waited for LDS -- 235 instead of 256 Gpixel/s")
         c = golden_case("fruit_tiled_3840x2160_q50_cds")
         run("natural statistics, strict: fruit.ppm tiled to 3840x2160, 128 frames per call, q50, chroma averaging on", W, H, 128, 50,
             jpeg.F_DEFAULT, fruit, {"n_bits": c["n_bits"], "sha_ascii": c["sha256_ascii_bits"], "cap": 8 << 20,

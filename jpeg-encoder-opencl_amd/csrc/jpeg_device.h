@@ -67,7 +67,7 @@ hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams&
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint32_t* meta, const uint32_t* pass_off, const uint32_t* arena,
                         const uint32_t* lut, const uint64_t* tile_off,
                         uint8_t* out, uint64_t out_stride, const uint64_t* frame_bits /* ~0: the frame is skipped */,
-                        uint32_t lds_words_limit, hipStream_t s);
+                        uint32_t lds_words_limit, bool small_window /* two workgroups per CU beside the block encode */, hipStream_t s);
 
 // auxiliary kernels (jpeg_aux_kernels.hip)
 hipError_t launch_lcg_fill(uint8_t* dst, uint64_t frame_bytes, uint32_t n_frames, uint32_t seed0, hipStream_t s);

@@ -698,6 +698,36 @@ __device__ __forceinline__ void load_look_fragments(const ScreenParams& sp, uint
         }
 }
 
+// The second look of screen_quantise (rare, wave-uniform): all five digits, fp64.  tt = the first look's thr^2 - d^2.
+__device__ __forceinline__ void second_look(const v4i (&acc)[kLookDigits], const int (&t)[4], const float (&tt)[4], const v4i& B,
+                                            const ScreenParams& sp, uint32_t ct, int mt, uint32_t gq, uint32_t lane,
+                                            uint32_t (&qb)[4], bool& amb) {
+    bool a1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a1[r] = !(tt[r] > 0.0f);
+    if (lane == 0) atomicAdd(&sp.stats[0], 1ull);
+    const uint4 t1 = sp.afrag[(mt * kScreenLimbs + 1) * 64 + lane], t0 = sp.afrag[(mt * kScreenLimbs) * 64 + lane];
+    const v4i acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w}, B,
+                                                           v4i{0, 0, 0, 0}, 0, 0, 0);
+    const v4i acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w}, B,
+                                                           v4i{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (a1[r]) {
+            // {s1, thr1, s2, thr2} of this position: read from memory, the second look is rare
+            const double* qc = sp.qconst + ((size_t)ct * 64 + 16 * mt + 4 * gq + r) * 4;
+            const double y1 = (double)acc[2][r] * 65536.0 + (double)t[r];                 // exact (< 2^37)
+            const double y2 = y1 * 65536.0 + (double)(acc1[r] * 256 + acc0[r]);          // exact (< 2^53)
+            const double z = y2 * qc[2];
+            const double tz = __builtin_fabs(z) + 0.5;
+            const double fr = tz - __builtin_floor(tz);
+            const int nn = (int)tz;
+            qb[r] = (uint32_t)(z < 0.0 ? -nn : nn);
+            amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
+        }
+    }
+}
+
 template <bool STD>
 __device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], const v4i& B, const ScreenParams& sp,
                                                 const float* __restrict__ qf /* LDS: sf[4], thr[4] of these positions */,
@@ -716,6 +746,23 @@ __device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], con
     }
     const v2f sA = {qf[0], qf[1]}, sB = {qf[2], qf[3]};
     const v2f M2 = {12582912.0f, 12582912.0f};
+    if constexpr (!STD) {
+        // Strict mode, fused: a = fl(fv * sf + 1.5 * 2^23) is the magic number plus the nearest integer rn of the EXACT
+        // product, d = fl(fv * sf - rn) that product's distance from it (one rounding each, where the unfused form rounds
+        // the product first and measures the distance of ITS nearest integer): every error bound of the text above holds
+        // with room to spare, and each pair of positions costs four packed instructions instead of five.
+        const v2f aA = __builtin_elementwise_fma(fA, sA, M2), aB = __builtin_elementwise_fma(fB, sB, M2);
+        const v2f rA = aA - M2, rB = aB - M2;
+        const v2f dA = __builtin_elementwise_fma(fA, sA, -rA), dB = __builtin_elementwise_fma(fB, sB, -rB);
+        const v2f hA = {qf[4], qf[5]}, hB = {qf[6], qf[7]};
+        const v2f tA = __builtin_elementwise_fma(-dA, dA, hA), tB = __builtin_elementwise_fma(-dB, dB, hB);
+        float tt[4] = {tA[0], tA[1], tB[0], tB[1]};
+        if (mt == 0 && gq == 0) tt[0] = 1.0f;  // coefficient 0: overwritten by the caller, never judged here
+        qb[0] = __float_as_uint(aA[0]), qb[1] = __float_as_uint(aA[1]), qb[2] = __float_as_uint(aB[0]), qb[3] = __float_as_uint(aB[1]);  // 0x4B400000 + q
+        const float tmin = __builtin_fminf(__builtin_fminf(__builtin_fminf(tt[0], tt[1]), tt[2]), tt[3]);
+        if (wave_any(!(tmin > 0.0f))) second_look(acc, t, tt, B, sp, ct, mt, gq, lane, qb, amb);
+        return;
+    }
     const v2f zA = fA * sA, zB = fB * sB;
     const v2f aA = zA + M2, aB = zB + M2;
     const float aa[4] = {aA[0], aA[1], aB[0], aB[1]};
@@ -728,46 +775,6 @@ __device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], con
 #pragma unroll
         for (int r = 0; r < 4; ++r) qb[r] = __float_as_uint(aa[r]);  // 0x4B400000 + q
         return;
-    }
-    const v2f rA = aA - M2, rB = aB - M2;
-    const v2f dA = zA - rA, dB = zB - rB;  // exact: zf and its nearest integer are within 1/2 of each other
-    // Accept test |d| < thr as thr^2 - d^2 > 0: one packed fma per pair of positions (the sign of an fma's exact value
-    // survives its rounding), the smallest of the four by a three-input minimum, ONE compare per lane.  thr^2 comes from the
-    // host rounded DOWN and already carries the |zf| 2^-21 term at the row's largest |zf|.
-    const v2f hA = {qf[4], qf[5]}, hB = {qf[6], qf[7]};
-    const v2f tA = __builtin_elementwise_fma(-dA, dA, hA), tB = __builtin_elementwise_fma(-dB, dB, hB);
-    float tt[4] = {tA[0], tA[1], tB[0], tB[1]};
-    if (mt == 0 && gq == 0) tt[0] = 1.0f;  // coefficient 0: overwritten by the caller, never judged here
-#pragma unroll
-    for (int r = 0; r < 4; ++r) qb[r] = __float_as_uint(aa[r]);  // 0x4B400000 + q
-    const float tmin = __builtin_fminf(__builtin_fminf(__builtin_fminf(tt[0], tt[1]), tt[2]), tt[3]);
-    if (wave_any(!(tmin > 0.0f))) {
-        bool a1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a1[r] = !(tt[r] > 0.0f);
-        if (lane == 0) atomicAdd(&sp.stats[0], 1ull);
-        const uint4 t1 = sp.afrag[(mt * kScreenLimbs + 1) * 64 + lane], t0 = sp.afrag[(mt * kScreenLimbs) * 64 + lane];
-        const v4i acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t1.x, (int)t1.y, (int)t1.z, (int)t1.w}, B,
-                                                               v4i{0, 0, 0, 0}, 0, 0, 0);
-        const v4i acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(v4i{(int)t0.x, (int)t0.y, (int)t0.z, (int)t0.w}, B,
-                                                               v4i{0, 0, 0, 0}, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (a1[r]) {
-                // {s1, thr1, s2, thr2} of this position: read from memory, the second look is rare
-                const double* qc = sp.qconst + ((size_t)ct * 64 + 16 * mt + 4 * gq + r) * 4;
-                const double y1 = (double)acc[2][r] * 65536.0 + (double)t[r];                 // exact (< 2^37)
-                const double y2 = y1 * 65536.0 + (double)(acc1[r] * 256 + acc0[r]);          // exact (< 2^53)
-                {
-                    const double z = y2 * qc[2];
-                    const double tt = __builtin_fabs(z) + 0.5;
-                    const double fr = tt - __builtin_floor(tt);
-                    const int nn = (int)tt;
-                    qb[r] = (uint32_t)(z < 0.0 ? -nn : nn);
-                    amb = amb || !(__builtin_fabs(fr - 0.5) < qc[3]);
-                }
-            }
-        }
     }
 }
 

@@ -604,7 +604,16 @@ __device__ __forceinline__ int meta_pred(const uint32_t* __restrict__ meta, size
 // allow -- 72 instead of the 32 it uses (.amdhsa_next_free_vgpr 65) -- and with 72 a k_merge wave only fits beside two
 // k_screen_encode waves of at most 216 registers (found in round 4 when the encode kernel went to 221 and batched calls
 // lost a quarter; tests/test_kernel_budget.py reads the allocation from the kernel descriptors now).
-template <bool S420>
+// SMALL: the bit-assembly window at half size (kEmitLdsWordsSmall), so that TWO workgroups of this kernel fit a CU beside
+// two of k_screen_encode: batches run this form.  With one workgroup per CU the merge of a part takes about as long as
+// the block encode it runs beside, and whenever it takes longer -- parts of unequal size, say 124 frames per call -- its
+// workgroups are still streaming through the CUs when the NEXT launch's persistent workgroups arrive: a CU that holds
+// two of them has no room for its second encode workgroup (72 KB of LDS), and that workgroup stays out until the
+// following k_merge is through as well (rocprofv3 timeline, gpurun r4tl: launches of 540-830 us instead of 500; 232
+// instead of 256 Gpixel/s at 100, 124, 132 frames per call).  At two per CU the merge is done well before the launch it
+// runs beside (gpurun r4w2: 256 Gpixel/s at every batch size tried).  Tiles beyond 64 000 bits (15.6 bit per pixel)
+// assemble their bits in device memory instead.
+template <bool S420, bool SMALL>
 __global__ void __launch_bounds__(S420 ? 384 : 256)
     k_merge(Geom g, const uint32_t* __restrict__ meta, const uint32_t* __restrict__ pass_off, const uint32_t* __restrict__ arena,
             const uint32_t* __restrict__ lut, const uint64_t* __restrict__ tile_off,
@@ -614,7 +623,7 @@ __global__ void __launch_bounds__(S420 ? 384 : 256)
     __builtin_amdgcn_s_setprio(3);  // see k_dc_heads
     // the 4:2:0 form gives up 256 window words for its longer offset array, so that both forms stay
     // within the 17.9 KiB a CU has left next to two resident workgroups of k_screen_encode
-    constexpr uint32_t kWindow = S420 ? kEmitLdsWords - 256 : kEmitLdsWords;
+    constexpr uint32_t kWindow = (SMALL ? kEmitLdsWordsSmall : kEmitLdsWords) - (S420 ? 256 : 0);
     __shared__ uint32_t s_dc[2][16];
     __shared__ uint32_t s_bits[NT];
     __shared__ uint32_t s_words[kWindow];
@@ -803,14 +812,19 @@ hipError_t launch_dc_heads(const Geom& g, uint32_t n_frames, const ScreenParams&
 hipError_t launch_merge(const Geom& g, uint32_t n_frames, const uint32_t* meta, const uint32_t* pass_off, const uint32_t* arena,
                         const uint32_t* lut, const uint64_t* tile_off,
                         uint8_t* out, uint64_t out_stride, const uint64_t* frame_bits, uint32_t lds_words_limit,
-                        hipStream_t s) {
+                        bool small_window, hipStream_t s) {
     if (lds_words_limit > kEmitLdsWords) lds_words_limit = kEmitLdsWords;
-    if (is420(g))
-        hipLaunchKernelGGL(k_merge<true>, dim3(g.tiles, n_frames), dim3(384), 0, s, g, meta, pass_off, arena, lut,
-                           tile_off, out, out_stride, frame_bits, lds_words_limit);
-    else
-        hipLaunchKernelGGL(k_merge<false>, dim3(g.tiles, n_frames), dim3(192), 0, s, g, meta, pass_off, arena, lut,
-                           tile_off, out, out_stride, frame_bits, lds_words_limit);
+#define MI355_LAUNCH_MERGE(S4, SM, NT) \
+    hipLaunchKernelGGL((k_merge<S4, SM>), dim3(g.tiles, n_frames), dim3(NT), 0, s, g, meta, pass_off, arena, lut, tile_off, out, \
+                       out_stride, frame_bits, lds_words_limit)
+    if (is420(g)) {
+        if (small_window) MI355_LAUNCH_MERGE(true, true, 384);
+        else MI355_LAUNCH_MERGE(true, false, 384);
+    } else {
+        if (small_window) MI355_LAUNCH_MERGE(false, true, 192);
+        else MI355_LAUNCH_MERGE(false, false, 192);
+    }
+#undef MI355_LAUNCH_MERGE
     return hipGetLastError();
 }
 

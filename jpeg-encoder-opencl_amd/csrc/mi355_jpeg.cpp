@@ -568,7 +568,7 @@ int launch_tails(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p, const Scr
                              true, s));
     if (rec) record(c, 3, s);
     HIP_TRY(launch_merge(g, p.nf, sp.meta, sp.pass_off, sp.arena, sp.lut, c->d_tile_off + (size_t)p.f0 * (g.tiles + 1),
-                         d_out + (size_t)p.f0 * out_stride, out_stride, d_bits + p.f0, c->emit_lds_words, s));
+                         d_out + (size_t)p.f0 * out_stride, out_stride, d_bits + p.f0, c->emit_lds_words, batch_frames > p.nf, s));
     if (rec) record(c, 4, s);
     return MI355_OK;
 }
@@ -608,11 +608,12 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         const uint32_t need_parts = (uint32_t)((n_frames + max_pf - 1) / max_pf);
         if (nparts < need_parts) nparts = need_parts;
     }
+    // Part boundaries: part i = frames [cut[i], cut[i + 1]).  (Ending the batch on a short part, whose tail kernels -- the
+    // only ones nothing hides -- are short too, was tried and is not faster: gpurun r4tp.)
+    std::vector<uint32_t> cut(1, 0u);
+    for (uint32_t i = 1; i <= nparts; ++i) cut.push_back((uint32_t)(((uint64_t)n_frames * i) / nparts));
     uint32_t max_nf = 0;
-    for (uint32_t i = 0; i < nparts; ++i) {
-        const uint32_t nf = (uint32_t)(((uint64_t)n_frames * (i + 1)) / nparts) - (uint32_t)(((uint64_t)n_frames * i) / nparts);
-        max_nf = nf > max_nf ? nf : max_nf;
-    }
+    for (uint32_t i = 0; i < nparts; ++i) max_nf = cut[i + 1] - cut[i] > max_nf ? cut[i + 1] - cut[i] : max_nf;
     const ArenaPlan big = plan_arena(c, g, max_nf, (size_t)max_nf * frame_words, (size_t)max_nf * by_units);
     const size_t set_arena = (big.total_words + 63) & ~(size_t)63;
     const size_t set_meta = meta_words(g, max_nf);
@@ -652,13 +653,15 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     c->last_launches = nparts;
     for (uint32_t i = 0; i < nparts; ++i) {
         BatchPart part;
-        part.f0 = (uint32_t)(((uint64_t)n_frames * i) / nparts);
-        part.nf = (uint32_t)(((uint64_t)n_frames * (i + 1)) / nparts) - part.f0;
+        part.f0 = cut[i];
+        part.nf = cut[i + 1] - cut[i];
         part.plan = plan_arena(c, g, part.nf, (size_t)part.nf * frame_words, (size_t)part.nf * by_units);
         part.set = i % nsets;
         part.counter = part.set;
         const ScreenParams sp = part_params(c, g, part, set_meta, set_arena);
         if (i >= nsets) HIP_TRY(hipStreamWaitEvent(s, c->ev_set[part.set], 0));  // the tails of part i - nsets are done with this set
+        // (Making this launch wait for the tails of part i - 2 -- they normally end a few per cent before block encode
+        // i - 1 does -- costs 8 %: the wait keeps two block-encode launches from running back to back.  gpurun r4f.)
         HIP_TRY(launch_screen_encode(g, part.nf, d_rgb + (size_t)part.f0 * g.frame_stride, sp, false, c->screen_waves, s));
         if (i + 1 == nparts) {  // the last part's tails stay on the caller's stream
             record(c, 1, s);
