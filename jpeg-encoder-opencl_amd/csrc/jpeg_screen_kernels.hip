@@ -708,11 +708,11 @@ __global__ void __launch_bounds__(S420 ? 384 : 256)
 #pragma unroll
     for (int i = 0; i < 4; ++i) pre[i] = (uint32_t)i * 32u < aclen ? arena[moff + i] : 0u;
     __syncthreads();
-    // tile-local exclusive offsets in scan order
-    uint32_t dcl = 0;
+    // tile-local exclusive offsets in scan order; the DC symbol is formed once and kept (code | value bits, right-aligned)
+    uint32_t dsym = 0, dcl = 0;
     {
-        auto count = [&](uint32_t, uint32_t len) { dcl += len; };
-        put_dc(dc - pred, s_dc[chroma ? 1 : 0], count);
+        auto keep = [&](uint32_t code, uint32_t len) { dsym = code, dcl = len; };
+        put_dc(dc - pred, s_dc[chroma ? 1 : 0], keep);
     }
     s_bits[spos] = active ? dcl + aclen : 0u;
     __syncthreads();
@@ -729,34 +729,44 @@ __global__ void __launch_bounds__(S420 ? 384 : 256)
     }
     __syncthreads();
     if (active) {
+        // The unit's bits go into the (zeroed) window by OR, a word at a time: the DC symbol at its bit position, then the
+        // AC string -- whole words as they lie in the arena (left-aligned, zero beyond the string's end), each funnelled
+        // with its predecessor to the string's bit phase: one v_alignbit_b32 and one LDS OR per word, no 64-bit
+        // accumulator, no length bookkeeping.  (This kernel's instructions are issued on the SIMDs the block encode of the
+        // next part runs on: until round 4 it took 270 vector and 200 scalar instructions per wave of 64 units, an eighth of
+        // the encode kernel's own.)
         const uint32_t pos = (uint32_t)(start & 31) + s_bits[spos];  // bits from the first word of the tile: below 2^21
         // restart intervals end on a byte boundary, filled with 1s (their start is aligned)
         const uint32_t fill = restart && tile_end ? (8u - ((pos + dcl + aclen) & 7u)) & 7u : 0u;
-        auto body = [&](auto& bw) {
-            auto put = [&](uint32_t code, uint32_t len) { bw.put(code, len); };
-            put_dc(dc - pred, s_dc[chroma ? 1 : 0], put);
+        auto body = [&](auto&& orw) {
+            if (dcl) {
+                const uint32_t d = dsym << (32u - dcl), sh = pos & 31u;  // left-aligned; dcl <= 27
+                orw(pos >> 5, d >> sh);
+                if (sh + dcl > 32u) orw((pos >> 5) + 1u, d << (32u - sh));
+            }
+            const uint32_t pa = pos + dcl, sa = pa & 31u, ja = pa >> 5;
+            uint32_t prev = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if ((uint32_t)i * 32u < aclen) {
-                    uint32_t len = aclen - i * 32u < 32u ? aclen - i * 32u : 32u;
-                    bw.put(pre[i] >> (32u - len), len);
+            for (uint32_t i = 0; i < 4; ++i) {
+                if (i * 32u < aclen) {
+                    orw(ja + i, __builtin_amdgcn_alignbit(prev, pre[i], sa));  // (prev : word) >> sa
+                    prev = pre[i];
                 }
             }
-            for (uint32_t done = 128; done < aclen; done += 32) {
-                uint32_t w = arena[moff + (done >> 5)];
-                uint32_t len = aclen - done < 32u ? aclen - done : 32u;
-                bw.put(w >> (32u - len), len);
+            for (uint32_t k = 4; k * 32u < aclen; ++k) {
+                const uint32_t w = arena[moff + k];
+                orw(ja + k, __builtin_amdgcn_alignbit(prev, w, sa));
+                prev = w;
             }
-            if (fill) bw.put((1u << fill) - 1u, fill);
-            bw.flush();
+            // what the shift pushed out of the string's last word (its ((aclen - 1) & 31) + 1 valid bits reach beyond bit 31)
+            if (aclen && ((aclen - 1u) & 31u) + sa >= 32u) orw(ja + ((aclen + 31u) >> 5), prev << (32u - sa));
+            if (fill) {
+                const uint32_t e = pa + aclen;
+                orw(e >> 5, (((1u << fill) - 1u) << (32u - fill)) >> (e & 31u));
+            }
         };
-        if (use_lds) {
-            BitWriterLds bw{s_words, 0, pos & 31, pos >> 5};
-            body(bw);
-        } else {
-            BitWriterGlobal bw{outw, 0, (uint32_t)(pos & 31), w0 + (pos >> 5)};
-            body(bw);
-        }
+        if (use_lds) body([&](uint32_t j, uint32_t v) { atomicOr(&s_words[j], v); });
+        else body([&](uint32_t j, uint32_t v) { atomicOr(&outw[w0 + j], __builtin_bswap32(v)); });
     }
     if (!use_lds) return;
     __syncthreads();
