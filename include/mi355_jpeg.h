@@ -184,7 +184,7 @@ int mi355_jpeg_encode_scan(mi355_jpeg_ctx *ctx, const uint8_t *rgb, uint32_t W, 
  * n_frames: 1 .. 65535, any out_stride >= 8 (a multiple of 4); a batch is never refused for its
  * size: it is cut into parts of ~16 4K frames' worth of pixels, each with 32-bit offsets of its own.
  * Device memory the library allocates for a call (kept for later calls, grown on demand): per frame
- * of a part 8 bytes per unit (units = 8x8 blocks x 3) plus 2 x min(9/16 x out_stride + 4 x units,
+ * of a part 4 bytes per unit (units = 8x8 blocks x 3) plus 2 x min(9/16 x out_stride + 4 x units,
  * 216 x units) + 0.25 MiB of string arena; one such set per part while the sets fit a quarter of the
  * free device memory (at most 32 GB), otherwise as many as fit and parts take turns (a little slower:
  * a part then waits for the tail kernels of the part whose set it reuses); plus 12 bytes per tile (64
