@@ -154,6 +154,7 @@ struct mi355_jpeg_ctx {
     uint32_t* d_lut2 = nullptr;     // [2 modes][2][66][16] whole AC symbols for |value| <= 31
     uint32_t* d_counters = nullptr; // [64] arena overflow-pool words, one per part in flight
     uint32_t max_sets = 0;          // MI355_JPEG_MAX_SETS (tests): upper limit of the workspace sets of a batch (0 = none)
+    int taper = -1;                 // MI355_JPEG_TAPER: size of a part in per cent of the part in front (0 = equal parts; -1: the default of the mode)
     uint32_t stagger = 0;           // MI355_JPEG_STAGGER (timing experiment, 0..64): later-dispatched workgroups start this many sleeps late
     unsigned long long* d_stats = nullptr;  // [0] second looks, [1] exact units, [2] rewalked units, [3] general-loop passes (mi355_jpeg_screen_stats)
     uint32_t last_launches = 0;     // block-encode launches of the last encode call
@@ -546,13 +547,15 @@ struct BatchPart {
     ArenaPlan plan;
     uint32_t set;      // workspace set of this part
     uint32_t counter;  // its overflow-pool counter (re-armed by the part's tile scan)
+    size_t meta_off, arena_off;  // where the set lies in d_meta / d_arena (words)
+    uint32_t set_nf;             // frames the set's metadata was laid out for
 };
 
-ScreenParams part_params(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p, size_t set_meta, size_t set_arena) {
+ScreenParams part_params(mi355_jpeg_ctx* c, const Geom& g, const BatchPart& p) {
     ScreenParams sp = screen_params(c, g, p.nf, p.plan, nullptr);
-    sp.meta = c->d_meta + (size_t)p.set * set_meta;
-    sp.pass_off = sp.meta + set_meta / 65 * 64;  // behind the unit words of the set's largest part
-    sp.arena = c->d_arena + (size_t)p.set * set_arena;
+    sp.meta = c->d_meta + p.meta_off;
+    sp.pass_off = sp.meta + meta_slots(g, p.set_nf);  // behind the unit words of the largest part the set holds
+    sp.arena = c->d_arena + p.arena_off;
     sp.counters = c->d_counters + p.counter;
     sp.tile_bits = c->d_tile_bits + (size_t)p.f0 * g.tiles;
     return sp;
@@ -608,37 +611,109 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         const uint32_t need_parts = (uint32_t)((n_frames + max_pf - 1) / max_pf);
         if (nparts < need_parts) nparts = need_parts;
     }
-    // Part boundaries: part i = frames [cut[i], cut[i + 1]).  (Ending the batch on a short part, whose tail kernels -- the
-    // only ones nothing hides -- are short too, was tried and is not faster: gpurun r4tp.)
-    std::vector<uint32_t> cut(1, 0u);
-    for (uint32_t i = 1; i <= nparts; ++i) cut.push_back((uint32_t)(((uint64_t)n_frames * i) / nparts));
-    uint32_t max_nf = 0;
-    for (uint32_t i = 0; i < nparts; ++i) max_nf = cut[i + 1] - cut[i] > max_nf ? cut[i + 1] - cut[i] : max_nf;
-    const ArenaPlan big = plan_arena(c, g, max_nf, (size_t)max_nf * frame_words, (size_t)max_nf * by_units);
-    const size_t set_arena = (big.total_words + 63) & ~(size_t)63;
-    const size_t set_meta = meta_words(g, max_nf);
+    // Part boundaries: part i = frames [cut[i], cut[i + 1]).
+    //
+    // Tapered (the ratio of a part to the part in front, in per cent; batches of five parts or more): every part's tail
+    // kernels run under the NEXT part's block encode -- except the last part's, which nothing hides -- so the batch should
+    // end on a short part; but a part's merge, beside an encode launch, takes 0.6 of the time that launch needs for the
+    // same number of frames (strict mode, q50: 19 against 31 us per 4K frame), so a part may not be much shorter than that
+    // fraction of the part in front or THAT part's tails stick out instead (which is why a short last part behind equal
+    // parts gained nothing, gpurun r4tp).  Sizes therefore fall geometrically to a last part of ~32 Mpixel; the first part
+    // takes what is left (nothing runs beside it).  The ratio that pays depends on merge time over encode time, i.e. on
+    // mode and bit rate (tools/taper_probe.py, gpurun r4tj; 128 4K frames, Gpixel/s at ratio 0 / 55 / 62 / 70): strict
+    // q25 286 / 292 / 290 / 290, q50 260 / 264 / 262 / 262, q75 216 / 207 / 219 / 221, q90 164 / 155 / 167 / 167; standard
+    // 4:4:4 q50 282 / 258 / 250 / 274, 4:2:0 q50 450 / 425 / 404 / 444, 4:2:0 q90 117 / 123 / 128 / 124 -- so strict mode
+    // runs at 70 (never behind equal parts) and the standard modes, whose block encode is twice as fast for the same
+    // merge, with equal parts.  Tapered parts get workspace sets of their own sizes; when those do not fit the memory
+    // budget the batch falls back to equal parts that share equal sets.
+    const uint32_t taper = c->taper >= 0 ? (uint32_t)c->taper : ((g.flags & MI355_F_STANDARD) ? 0u : 70u);
+    std::vector<uint32_t> cut;
+    auto equal_cut = [&]() {
+        cut.assign(1, 0u);
+        for (uint32_t i = 1; i <= nparts; ++i) cut.push_back((uint32_t)(((uint64_t)n_frames * i) / nparts));
+    };
+    const uint64_t frame_px = (uint64_t)g.W * g.H;
+    bool tapered = false;
+    const uint32_t nparts_equal = nparts;
+    if (taper && nparts >= 5) {
+        std::vector<uint32_t> rev;  // sizes from the last part backwards
+        double x = (double)(((1ull << 25) + frame_px / 2) / frame_px);
+        if (x < 1.0) x = 1.0;
+        uint32_t sum = 0;
+        while (sum + (uint32_t)(x + 0.5) < n_frames) {
+            rev.push_back((uint32_t)(x + 0.5));
+            sum += rev.back();
+            x = x * 100.0 / taper;
+        }
+        rev.push_back(n_frames - sum);  // the first part: at most the next size of the series
+        bool fits32 = true;
+        for (uint32_t nf : rev) fits32 = fits32 && (uint64_t)nf * (frame_words + by_units + (1u << 16)) < (1ull << 32) - (1ull << 24);
+        if (fits32 && rev.size() >= 3 && rev.size() <= kCounters) {
+            cut.assign(1, 0u);
+            for (size_t k = rev.size(); k-- > 0;) cut.push_back(cut.back() + rev[k]);
+            nparts = (uint32_t)rev.size();
+            tapered = true;
+        }
+    }
+    if (!tapered) equal_cut();
     // Sets of {metadata, arena}: one per part while they fit a budget (a quarter of the free device memory, at most
     // 32 GB), otherwise as many as fit (at least 2) and part i reuses the set of part i - nsets once that part's tail
     // kernels are done.  (Reuse costs: the wait for the side stream between two block-encode launches keeps them from
     // running back to back -- 8 % on the bench with two alternating sets -- so sets are only shared when they must be.)
-    uint32_t nsets = nparts;
+    size_t budget = (size_t)32 << 30;
     if (nparts > 2) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0, (void)hipGetLastError();
         free_b += c->meta_cap * sizeof(uint32_t) + c->arena_cap * sizeof(uint32_t);  // what this context holds already counts as free
-        size_t budget = free_b / 4 < ((size_t)32 << 30) ? free_b / 4 : ((size_t)32 << 30);
-        const size_t set_bytes = (set_meta + set_arena) * sizeof(uint32_t);
-        const size_t fit = set_bytes ? budget / set_bytes : nparts;
-        nsets = (uint32_t)(fit < 2 ? 2 : (fit < nparts ? fit : nparts));
-        if (c->max_sets && nsets > c->max_sets) nsets = c->max_sets;  // tests
+        if (free_b / 4 < budget) budget = free_b / 4;
     }
-    // the overflow counter belongs to the set: the wait that guards a set's reuse then also orders the counter's re-arm
-    // (part i's tile scan) before part i + nsets allocates from it
-    if (nsets > kCounters) nsets = kCounters;
-    if (set_arena > 0xFFFFFFFFull) return MI355_E_ARG;  // (cannot happen: parts were sized for it)
+    auto arena_of = [&](uint32_t nf) {
+        const ArenaPlan pl = plan_arena(c, g, nf, (size_t)nf * frame_words, (size_t)nf * by_units);
+        return (pl.total_words + 63) & ~(size_t)63;
+    };
+    std::vector<size_t> meta_off, arena_off;  // per SET, in words; one entry more: the totals
+    std::vector<uint32_t> set_nf;
+    uint32_t nsets = nparts;
+    for (;;) {
+        meta_off.assign(1, 0), arena_off.assign(1, 0), set_nf.clear();
+        if (tapered) {  // a set per part, each of its part's size
+            for (uint32_t i = 0; i < nparts; ++i) {
+                set_nf.push_back(cut[i + 1] - cut[i]);
+                meta_off.push_back(meta_off.back() + meta_words(g, set_nf.back()));
+                arena_off.push_back(arena_off.back() + arena_of(set_nf.back()));
+            }
+            if (c->max_sets && nparts > c->max_sets) tapered = false;  // tests: shared sets
+            else if ((meta_off.back() + arena_off.back()) * sizeof(uint32_t) <= budget || nparts <= 2) break;
+            tapered = false;  // does not fit: equal parts, shared sets
+            nparts = nparts_equal;
+            equal_cut();
+            continue;
+        }
+        uint32_t max_nf = 0;
+        for (uint32_t i = 0; i < nparts; ++i) max_nf = cut[i + 1] - cut[i] > max_nf ? cut[i + 1] - cut[i] : max_nf;
+        const size_t set_meta = meta_words(g, max_nf), set_arena = arena_of(max_nf);
+        nsets = nparts;
+        if (nparts > 2) {
+            const size_t set_bytes = (set_meta + set_arena) * sizeof(uint32_t);
+            const size_t fit = set_bytes ? budget / set_bytes : nparts;
+            nsets = (uint32_t)(fit < 2 ? 2 : (fit < nparts ? fit : nparts));
+            if (c->max_sets && nsets > c->max_sets) nsets = c->max_sets;  // tests
+        }
+        // the overflow counter belongs to the set: the wait that guards a set's reuse then also orders the counter's re-arm
+        // (part i's tile scan) before part i + nsets allocates from it
+        if (nsets > kCounters) nsets = kCounters;
+        if (set_arena > 0xFFFFFFFFull) return MI355_E_ARG;  // (cannot happen: parts were sized for it)
+        for (uint32_t k = 0; k < nsets; ++k) {
+            set_nf.push_back(max_nf);
+            meta_off.push_back(meta_off.back() + set_meta);
+            arena_off.push_back(arena_off.back() + set_arena);
+        }
+        break;
+    }
+    if (tapered) nsets = nparts;
     int e;
-    if ((e = ensure(c->d_meta, c->meta_cap, set_meta * nsets))) return e;
-    if ((e = ensure(c->d_arena, c->arena_cap, set_arena * nsets))) return e;
+    if ((e = ensure(c->d_meta, c->meta_cap, meta_off.back()))) return e;
+    if ((e = ensure(c->d_arena, c->arena_cap, arena_off.back()))) return e;
     if (nparts > 1 && !c->side) {
         HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
@@ -658,7 +733,8 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
         part.plan = plan_arena(c, g, part.nf, (size_t)part.nf * frame_words, (size_t)part.nf * by_units);
         part.set = i % nsets;
         part.counter = part.set;
-        const ScreenParams sp = part_params(c, g, part, set_meta, set_arena);
+        part.meta_off = meta_off[part.set], part.arena_off = arena_off[part.set], part.set_nf = set_nf[part.set];
+        const ScreenParams sp = part_params(c, g, part);
         if (i >= nsets) HIP_TRY(hipStreamWaitEvent(s, c->ev_set[part.set], 0));  // the tails of part i - nsets are done with this set
         // (Making this launch wait for the tails of part i - 2 -- they normally end a few per cent before block encode
         // i - 1 does -- costs 8 %: the wait keeps two block-encode launches from running back to back.  gpurun r4f.)
@@ -711,6 +787,7 @@ struct Knobs {
     double tau_scale = 1.0;
     uint32_t batch_parts = 0xFFFFu;
     uint32_t max_sets = 0;
+    int taper = -1;
     uint32_t screen_waves = 0;  // 0: the device's default
     uint32_t stagger = 0;
 };
@@ -742,6 +819,10 @@ bool read_knobs(Knobs* k) {
     }
     if (knob_uint("MI355_JPEG_BATCH_PARTS", 1, 8, &kv)) k->batch_parts = (uint32_t)kv;
     if (knob_uint("MI355_JPEG_MAX_SETS", 2, 64, &kv)) k->max_sets = (uint32_t)kv;
+    if (knob_uint("MI355_JPEG_TAPER", 0, 95, &kv)) {  // scheduling only; 0 = equal parts
+        if (kv && kv < 40) bad = true;
+        else k->taper = (int)kv;
+    }
     if (knob_uint("MI355_JPEG_SCREEN_WAVES", 32, 8192, &kv)) {
         if (kv & 31) bad = true;
         else k->screen_waves = (uint32_t)kv;
@@ -823,6 +904,7 @@ static int create_body(int device_id, mi355_jpeg_ctx** out){
     c->tau_scale = kn.tau_scale;
     c->batch_parts = kn.batch_parts;
     c->max_sets = kn.max_sets;
+    c->taper = kn.taper;
     c->stagger = kn.stagger;
     if (kn.screen_waves) (void)mi355_jpeg_set_encode_waves(c, kn.screen_waves);  // one place derives every grid from it
     int e = MI355_OK;

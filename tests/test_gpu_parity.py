@@ -1139,6 +1139,48 @@ def test_parts_that_share_workspace_sets(jpeg, monkeypatch):
     e2.close()
 
 
+def test_tapered_parts_give_the_bits_of_equal_parts(jpeg, monkeypatch):
+    """Batches of five parts or more run in parts of falling size, each with a workspace set of its own size (strict mode's
+    default).  96 4K frames under three partitions -- the default taper (70), a steep one (45: a first part
+    that is smaller than the second) and equal parts -- must give the same bytes, and the reference build's goldens for the
+    frames that have one.  (test_parts_that_share_workspace_sets covers the fall-back to equal parts with shared sets.)"""
+    import torch
+    W, H, n = 3840, 2160, 96
+    gold = _golden(W, H, 50)
+    dev = torch.device("cuda", 0)
+    d_rgb = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    cap = 6 << 20
+    outs, parts = [], []
+    for taper in (None, "45", "0"):
+        if taper is None:
+            monkeypatch.delenv("MI355_JPEG_TAPER", raising=False)
+        else:
+            monkeypatch.setenv("MI355_JPEG_TAPER", taper)
+        e2 = jpeg.Encoder(0)
+        set_quality(e2, 50)
+        if not outs:
+            e2.synth_lcg_device(d_rgb.data_ptr(), W * H * 3, n, 1)
+        d_out = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
+        d_bits = torch.zeros(n, dtype=torch.int64, device=dev)
+        for _ in range(2):
+            e2.encode_scan_device(d_rgb.data_ptr(), W, H, n, d_out.data_ptr(), cap, d_bits.data_ptr())
+            e2.sync()
+        parts.append(e2.last_call_parts())
+        outs.append((d_bits.cpu().numpy().copy(), d_out))
+        e2.close()
+    assert parts[2] == 6 and parts[0] >= 5 and parts[1] >= 5 and len(set(parts)) >= 2, parts  # the partitions differ
+    bits0, out0 = outs[2]
+    checked = 0
+    for f in range(n):
+        if (f + 1) in gold:
+            nb, sha = gold[f + 1]
+            assert int(bits0[f]) == nb and ascii_sha(out0[f, :(nb + 7) // 8].cpu().numpy(), nb) == sha, f
+            checked += 1
+    assert checked >= 4
+    for b, o in outs[:2]:
+        assert np.array_equal(b, bits0) and torch.equal(o, out0)
+
+
 def test_batch_at_worst_case_capacity_is_accepted(jpeg, enc):
     """128 4K frames in ONE call with out_stride = mi355_jpeg_scan_bound (84 MB per frame, what
     the header recommends) used to be refused with MI355_E_ARG (the workspace was sized from the caller's capacity

@@ -272,13 +272,15 @@ def test_exactness_knobs_are_refused_before_any_device_is_touched(monkeypatch):
           [("MI355_JPEG_SCREEN_WAVES", v) for v in ("33", "0", "100000")] + \
           [("MI355_JPEG_BATCH_PARTS", v) for v in ("0", "9")] + \
           [("MI355_JPEG_STAGGER", v) for v in ("65", "-1", "2x")] + \
-          [("MI355_JPEG_MAX_SETS", v) for v in ("1", "65")]
+          [("MI355_JPEG_MAX_SETS", v) for v in ("1", "65")] + \
+          [("MI355_JPEG_TAPER", v) for v in ("39", "96", "-1", "x")]
     for name, v in bad:
         monkeypatch.setenv(name, v)
         assert create() == jpeg.E_ARG, (name, v)
         monkeypatch.delenv(name)
     good = [("MI355_JPEG_SCREEN_TAU_SCALE", "1"), ("MI355_JPEG_SCREEN_TAU_SCALE", "1e6"), ("MI355_JPEG_TRANSFORM_MODE", "0"),
-            ("MI355_JPEG_SCREEN_WAVES", "1024"), ("MI355_JPEG_STAGGER", "0"), ("MI355_JPEG_STAGGER", "64")]
+            ("MI355_JPEG_SCREEN_WAVES", "1024"), ("MI355_JPEG_STAGGER", "0"), ("MI355_JPEG_STAGGER", "64"),
+            ("MI355_JPEG_TAPER", "0"), ("MI355_JPEG_TAPER", "40"), ("MI355_JPEG_TAPER", "95")]
     for name, v in good:
         monkeypatch.setenv(name, v)
         assert create() == base, (name, v)
