@@ -542,7 +542,14 @@ def worker(args):
     # HIP events around the block-encode kernel launches of every call of the timed region, recorded by
     # the library on the launch stream (mode 2: two records per call)
     enc.set_profiling(2)
+    # markers for tools/profile_summary.py: a 256-byte k_lcg_fill launch on either side of the timed region (outside it: the
+    # region starts and ends on a device sync), so that a kernel trace of this command says WHICH launches were timed --
+    # the parts of a batch differ in size since round 4, so durations alone no longer do
+    marker = torch.empty(256, dtype=torch.uint8, device=dev)
+    enc.synth_lcg_device(marker.data_ptr(), 256, 1, 0x7ffffff1)
     dt = timed_region(step, args.steps, dist, distributed, sync)
+    enc.synth_lcg_device(marker.data_ptr(), 256, 1, 0x7ffffff2)
+    enc.sync()
     prof, calls = enc.profile_summary()
     enc.set_profiling(0)
     dt, per_rank = gather_times(dt, dist, distributed, coll_dev)

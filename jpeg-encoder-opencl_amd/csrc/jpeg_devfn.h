@@ -310,6 +310,22 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/
     v += dpp_src<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3
     return v;
 }
+// The same scan with the DPP operand inside the add (v_add_u32_dpp: six instructions).  Left to itself the compiler
+// combines `v += dpp_src(v)` that way in some kernels and not in others (k_merge: six moves of zero, six v_mov_b32_dpp,
+// six adds); bound_ctrl:1 makes lanes without a source read 0, lanes outside the row mask keep their value.  The s_nop
+// between the steps is the two wait states a DPP read needs behind the write of its operand.  All lanes must be active.
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    asm volatile(
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+}
 __device__ __forceinline__ void load_unit(const uint32_t* __restrict__ src, uint32_t (&c)[32]) {
 #pragma unroll
     for (int p = 0; p < 32; ++p) c[p] = src[p * 64];

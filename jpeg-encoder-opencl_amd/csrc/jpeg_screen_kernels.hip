@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(64)
 // ----------------------------------------------------------------------------
 // DC predictor of a unit from `meta`: the previous lane, or the last block of the previous tile.
 // ----------------------------------------------------------------------------
-__device__ __forceinline__ int meta_pred(const uint32_t* __restrict__ meta, size_t frame_tile0, uint32_t tile,
+__device__ __forceinline__ int meta_pred(const uint32_t* __restrict__ meta, uint32_t frame_tile0, uint32_t tile,
                                          uint32_t chan, uint32_t lane, int own_dc) {
     int prev = __shfl_up(own_dc, 1);
     if (lane == 0) {
@@ -626,14 +626,14 @@ __global__ void __launch_bounds__(S420 ? 384 : 256)
     constexpr uint32_t kWindow = (SMALL ? kEmitLdsWordsSmall : kEmitLdsWords) - (S420 ? 256 : 0);
     __shared__ uint32_t s_dc[2][16];
     __shared__ uint32_t s_bits[NT];
-    __shared__ uint32_t s_words[kWindow];
+    __shared__ alignas(16) uint32_t s_words[kWindow];
     const uint32_t tid = threadIdx.x, lane = tid & 63, chan = tid >> 6;
     const uint32_t tile = blockIdx.x, frame = blockIdx.y;
     // a frame with an error (k_tile_scan wrote its verdict in place of the bit count: over capacity, a size without a
     // code) is skipped as a whole; the other frames of the call are written in full
     if (frame_bits[frame] >= kBitsFlagged) return;
     if (lds_words_limit > kWindow) lds_words_limit = kWindow;
-    const size_t ft0 = (size_t)frame * g.tiles;
+    const uint32_t ft0 = frame * g.tiles;  // (slot indices in 32 bits: a part has fewer unit slots than arena words, and those are below 2^32)
     const uint64_t* to = tile_off + (size_t)frame * (g.tiles + 1);
     const uint64_t start = to[tile], end = to[tile + 1];
     const uint64_t w0 = start >> 5;
@@ -645,8 +645,9 @@ __global__ void __launch_bounds__(S420 ? 384 : 256)
     const uint32_t ptile = restart ? 0u : tile;        // "no previous tile" for the DC predictors
     const uint32_t last_blk = g.N - 1 - tile * 64 < 63 ? g.N - 1 - tile * 64 : 63;  // last active block / MCU
     if (tid < 32) s_dc[tid >> 4][tid & 15] = lut[(tid >> 4) * 256 + (tid & 15)];
-    if (use_lds) {
-        for (uint32_t i = tid; i < nw; i += NT) s_words[i] = 0;
+    if (use_lds) {  // (16 bytes per store; up to three words beyond nw: the window's size is a multiple of four)
+        static_assert(kWindow % 4 == 0, "the window is zeroed and written out four words at a time");
+        for (uint32_t i = tid * 4; i < nw; i += NT * 4) *reinterpret_cast<uint4*>(&s_words[i]) = make_uint4(0u, 0u, 0u, 0u);
     } else {
         for (uint32_t i = tid; i < nw; i += NT) {
             bool shared = (i == 0 && (start & 31)) || (i == nw - 1 && (end & 31) && !last_tile);
@@ -666,10 +667,10 @@ __global__ void __launch_bounds__(S420 ? 384 : 256)
     };
     if constexpr (S420) {
         const uint32_t mcu = tid / 6, k = tid - mcu * 6;
-        const size_t t0 = (ft0 + tile) * 6 * 64;
+        const uint32_t t0 = (ft0 + tile) * 6 * 64;
         {   // wave w = pass w of the tile: offsets in pass order through s_bits, picked up in scan order below
             const uint32_t need = words_of(meta[t0 + tid]);
-            s_bits[tid] = pass_off[(ft0 + tile) * 6 + (tid >> 6)] + wave_incl_scan(need, lane) - need;
+            s_bits[tid] = pass_off[(ft0 + tile) * 6 + (tid >> 6)] + wave_incl_scan_dpp(need) - need;
             __syncthreads();
         }
         spos = tid;
@@ -684,7 +685,7 @@ __global__ void __launch_bounds__(S420 ? 384 : 256)
             if (L > 0) pred = meta_dc(meta[t0 + L - 1]);
             else if (ptile > 0) pred = meta_dc(meta[t0 - 6 * 64 + 3 * 64 + 63]);
         } else {
-            const size_t slot = t0 + (size_t)k * 64 + mcu;
+            const uint32_t slot = t0 + k * 64 + mcu;
             mw = meta[slot];
             moff = s_bits[k * 64 + mcu];
             if (mcu > 0) pred = meta_dc(meta[slot - 1]);
@@ -698,15 +699,23 @@ __global__ void __launch_bounds__(S420 ? 384 : 256)
         tile_end = lane == last_blk && chan == 2;
         mw = meta[((ft0 + tile) * 3 + chan) * 64 + lane];
         const uint32_t need = words_of(mw);
-        moff = pass_off[(ft0 + tile) * 3 + chan] + wave_incl_scan(need, lane) - need;
+        moff = pass_off[(ft0 + tile) * 3 + chan] + wave_incl_scan_dpp(need) - need;
         dc = meta_dc(mw);
         pred = meta_pred(meta, ft0, ptile, chan, lane, dc);
         if (restart && lane == 0) pred = 0;
     }
     const uint32_t aclen = active ? (mw >> 16) : 0u;
-    uint32_t pre[4];
+    // the first four words of the string in ONE load (dword-aligned; the words behind a shorter string are read and not used:
+    // the arena ends in more than a kilobyte of slack per wave region)
+    struct __attribute__((packed, aligned(4))) Words4 {
+        uint32_t w[4];
+    };
+    uint32_t pre[4] = {0u, 0u, 0u, 0u};
+    if (aclen) {
+        const Words4 p4 = *reinterpret_cast<const Words4*>(arena + moff);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pre[i] = (uint32_t)i * 32u < aclen ? arena[moff + i] : 0u;
+        for (int i = 0; i < 4; ++i) pre[i] = p4.w[i];
+    }
     __syncthreads();
     // tile-local exclusive offsets in scan order; the DC symbol is formed once and kept (code | value bits, right-aligned)
     uint32_t dsym = 0, dcl = 0;
@@ -720,7 +729,7 @@ __global__ void __launch_bounds__(S420 ? 384 : 256)
         uint32_t a[UPB], sum = 0;
 #pragma unroll
         for (uint32_t i = 0; i < UPB; ++i) a[i] = s_bits[tid * UPB + i], sum += a[i];
-        uint32_t run = wave_incl_scan(sum, tid) - sum;
+        uint32_t run = wave_incl_scan_dpp(sum) - sum;
 #pragma unroll
         for (uint32_t i = 0; i < UPB; ++i) {
             s_bits[tid * UPB + i] = run;
@@ -770,13 +779,29 @@ __global__ void __launch_bounds__(S420 ? 384 : 256)
     }
     if (!use_lds) return;
     __syncthreads();
-    for (uint32_t i = tid; i < nw; i += NT) {
-        uint32_t v = __builtin_bswap32(s_words[i]);
-        bool shared = (i == 0 && (start & 31)) || (i == nw - 1 && (end & 31) && !last_tile);
-        if (shared) {
-            if (v) atomicOr(&outw[w0 + i], v);
+    // write-out, four words per thread and trip: one 16-byte LDS read, one 16-byte store where all four words are the
+    // tile's own (every group but the first and the last); the words a tile shares with its neighbours go by atomic OR
+    struct __attribute__((packed, aligned(4))) Out4 {
+        uint32_t w[4];
+    };
+    const bool share_first = (start & 31) != 0, share_last = (end & 31) != 0 && !last_tile;
+    for (uint32_t i = tid * 4; i < nw; i += NT * 4) {
+        const uint4 r = *reinterpret_cast<const uint4*>(&s_words[i]);
+        const uint32_t v[4] = {__builtin_bswap32(r.x), __builtin_bswap32(r.y), __builtin_bswap32(r.z), __builtin_bswap32(r.w)};
+        if (i > 0 && i + 4 < nw) {
+            *reinterpret_cast<Out4*>(&outw[w0 + i]) = Out4{{v[0], v[1], v[2], v[3]}};
         } else {
-            outw[w0 + i] = v;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t w = i + k;
+                if (w >= nw) break;
+                const bool shared = (w == 0 && share_first) || (w == nw - 1 && share_last);
+                if (shared) {
+                    if (v[k]) atomicOr(&outw[w0 + w], v[k]);
+                } else {
+                    outw[w0 + w] = v[k];
+                }
+            }
         }
     }
 }

@@ -4,6 +4,8 @@
 set -e
 OUT=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# equal parts (16 frames per launch): the summaries divide a launch's counters by its frames
+export MI355_JPEG_TAPER=0
 mkdir -p "$OUT"
 python3 -c "import bench; print(bench.kernel_sources_sha())" > "$OUT/kernel_sources_sha"
 PASSES=(

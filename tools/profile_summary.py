@@ -3,10 +3,9 @@
 (tools/gpu_round.sh ... prof) next to the JSON line bench.py printed in that same run:
 
   * per kernel: launches, average / min / max duration;
-  * the dominant kernel's launches of the TIMED REGION (the last steps x launches-per-step launches of the
-    batch shape -- the earlier ones of that shape are the isolated pre-region call and the warm-up; the short
-    ones belong to the single-call latency leg, the pool leg and the stage probes) and their average duration,
-    which bench.py's roofline.kernel_ms (HIP events on the launch stream inside the timed region) must agree with.
+  * the dominant kernel's launches of the TIMED REGION (those between the two marker launches bench.py puts around it)
+    and their average duration, which bench.py's roofline.kernel_ms (HIP events on the launch stream inside the timed
+    region, divided by the launches) must agree with.
 
 usage: profile_summary.py <gpurun_out/TAG> <out.json>"""
 import collections
@@ -29,17 +28,16 @@ kern = line["roofline"]["kernel"]
 dom = sorted(by[[k for k in by if k.startswith(kern + "<false, 0>") or k == kern][0]])
 steps, per_step = line["steps"], line["config"]["launches_of_dominant_kernel_per_step"]
 n_timed = steps * per_step
-# the batch-shape launches: the longest run of consecutive launches of similar duration (pre-region call, warm-up, timed region);
-# later launches of other durations belong to the latency leg and the pool leg (whose kernels share the device with copies)
-runs, cur = [], []
-for x in dom:
-    if cur and not (0.75 * cur[len(cur) // 2][1] <= x[1] <= 1.35 * cur[len(cur) // 2][1]):
-        runs.append(cur)
-        cur = []
-    cur.append(x)
-runs.append(cur)
-batch_shape = max(runs, key=len)
-timed = batch_shape[-n_timed:]
+# The timed region: the dominant kernel's launches between bench.py's two marker launches (k_lcg_fill on 256 bytes: the only
+# launches of that kernel with a grid of one workgroup).  The parts of a batch differ in size since round 4, so a launch's
+# duration no longer says which leg it belongs to.
+fills = sorted(by.get("k_lcg_fill", []))
+small = min(f[4] for f in fills)
+marks = [f[0] for f in fills if f[4] == small]
+assert len(marks) == 2, "expected the two marker launches of bench.py's timed region, found %d" % len(marks)
+timed = [x for x in dom if marks[0] < x[0] < marks[1]]
+batch_shape = timed
+assert len(timed) == n_timed, (len(timed), n_timed)
 avg_us = sum(d for _, d, *_ in timed) / len(timed)
 summary = {
     "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps %d --warmup %d" % (line["steps"], line["warmup"]),

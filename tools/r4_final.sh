@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU box helper (round 4): the round's evidence in one call.  usage: tools/r4_final.sh <tag> [steps...]
+# (the pmc, cfgpmc and overlap steps run with MI355_JPEG_TAPER=0: equal parts of 16 frames, which their summaries assume)
 # steps: test bench prof pmc cfgpmc overlap stamps   (default: all but stamps, which needs libmi355jpeg_stamps.so = a `make STAMPS=1` build).  Steps are joined with && semantics (set -e).
 set -e -o pipefail
 TAG=$1; shift
@@ -22,7 +23,7 @@ for STEP in $STEPS; do
         for P in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
                  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
                  "FETCH_SIZE" "WRITE_SIZE"; do
-          rocprofv3 --pmc $P --output-format csv -d "$OUT/pmc_$C/pass$i" -- python3 tools/config_bench.py $C > "$OUT/pmc_$C.pass$i.log" 2>&1
+          MI355_JPEG_TAPER=0 rocprofv3 --pmc $P --output-format csv -d "$OUT/pmc_$C/pass$i" -- python3 tools/config_bench.py $C > "$OUT/pmc_$C.pass$i.log" 2>&1
           i=$((i+1))
         done
         python3 tools/pmc_summary.py "$OUT/pmc_$C" > "$OUT/pmc_$C.summary.txt"
@@ -30,7 +31,7 @@ for STEP in $STEPS; do
         find "$OUT/pmc_$C" -name "*.csv" -size +8M -delete
       done ;;
     overlap)
-      rocprofv3 --kernel-trace --output-format csv -d "$OUT/overlap" -- python3 tools/overlap_probe.py > "$OUT/overlap.log" 2>&1 || { tail -20 "$OUT/overlap.log"; exit 1; }
+      MI355_JPEG_TAPER=0 rocprofv3 --kernel-trace --output-format csv -d "$OUT/overlap" -- python3 tools/overlap_probe.py > "$OUT/overlap.log" 2>&1 || { tail -20 "$OUT/overlap.log"; exit 1; }
       python3 tools/overlap_summary.py "$OUT/overlap" "$OUT/overlap_summary.json" ;;
     stamps)
       MI355_JPEG_LIB=$GRAFT_REPO_ROOT/jpeg-encoder-opencl_amd/libmi355jpeg_stamps.so python3 tools/stamps.py > "$OUT/stamps.txt" 2>&1 || { tail -20 "$OUT/stamps.txt"; exit 1; }; tail -8 "$OUT/stamps.txt" ;;

@@ -5,6 +5,8 @@
 set -e
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# equal parts (16 frames per launch): the summaries divide a launch's counters by its frames
+export MI355_JPEG_TAPER=0
 P=$GRAFT_REPO_ROOT/jpeg-encoder-opencl_amd
 PASSES=(
  "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
