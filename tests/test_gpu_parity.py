@@ -1151,9 +1151,13 @@ def test_tapered_parts_give_the_bits_of_equal_parts(jpeg, monkeypatch):
     d_rgb = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
     cap = 6 << 20
     outs, parts = [], []
-    for taper in (None, "45", "0"):
+    for taper in (None, "45", "0", "sets"):
+        monkeypatch.delenv("MI355_JPEG_MAX_SETS", raising=False)
         if taper is None:
             monkeypatch.delenv("MI355_JPEG_TAPER", raising=False)
+        elif taper == "sets":  # the default taper, but only two workspace sets allowed: falls back to equal parts sharing them
+            monkeypatch.delenv("MI355_JPEG_TAPER", raising=False)
+            monkeypatch.setenv("MI355_JPEG_MAX_SETS", "2")
         else:
             monkeypatch.setenv("MI355_JPEG_TAPER", taper)
         e2 = jpeg.Encoder(0)
@@ -1168,7 +1172,7 @@ def test_tapered_parts_give_the_bits_of_equal_parts(jpeg, monkeypatch):
         parts.append(e2.last_call_parts())
         outs.append((d_bits.cpu().numpy().copy(), d_out))
         e2.close()
-    assert parts[2] == 6 and parts[0] >= 5 and parts[1] >= 5 and len(set(parts)) >= 2, parts  # the partitions differ
+    assert parts[2] == 6 and parts[3] == 6 and parts[0] >= 5 and parts[1] >= 5 and len(set(parts)) >= 2, parts  # the partitions differ
     bits0, out0 = outs[2]
     checked = 0
     for f in range(n):
@@ -1177,8 +1181,42 @@ def test_tapered_parts_give_the_bits_of_equal_parts(jpeg, monkeypatch):
             assert int(bits0[f]) == nb and ascii_sha(out0[f, :(nb + 7) // 8].cpu().numpy(), nb) == sha, f
             checked += 1
     assert checked >= 4
-    for b, o in outs[:2]:
+    for b, o in outs[:2] + outs[3:]:
         assert np.array_equal(b, bits0) and torch.equal(o, out0)
+
+
+def test_batch_whose_tiles_overflow_the_half_window(jpeg, monkeypatch):
+    """Batches run k_merge with the half-size bit-assembly window (64 000 bits per tile); tiles beyond it assemble their bits
+    in device memory.  32 4K noise frames at q95 (two parts; ~19 bit per pixel: every tile overflows) against the oracle for
+    two of them, and against a context that is made to take the device-memory path for EVERY tile."""
+    import torch
+    W, H, n = 3840, 2160, 32
+    dev = torch.device("cuda", 0)
+    d_rgb = torch.empty((n, H, W, 3), dtype=torch.uint8, device=dev)
+    cap = 28 << 20
+    res = []
+    for words in (None, "0"):
+        if words is None:
+            monkeypatch.delenv("MI355_JPEG_EMIT_LDS_WORDS", raising=False)
+        else:
+            monkeypatch.setenv("MI355_JPEG_EMIT_LDS_WORDS", words)
+        e2 = jpeg.Encoder(0)
+        ql, qc = set_quality(e2, 95)
+        if not res:
+            e2.synth_lcg_device(d_rgb.data_ptr(), W * H * 3, n, 1)
+        d_out = torch.zeros((n, cap), dtype=torch.uint8, device=dev)
+        d_bits = torch.zeros(n, dtype=torch.int64, device=dev)
+        e2.encode_scan_device(d_rgb.data_ptr(), W, H, n, d_out.data_ptr(), cap, d_bits.data_ptr())
+        e2.sync()
+        assert e2.last_call_parts() == 2
+        res.append((d_bits.cpu().numpy().copy(), d_out))
+        e2.close()
+    bits, out = res[0]
+    assert (bits > 64000 * (W // 8) * (H // 8) // 64).all()  # more than 64 000 bits per tile on average
+    for f in (0, n - 1):
+        o = ol.oracle_encode(ol.lcg_frame(W, H, 1 + f), ql, qc, True)
+        assert int(bits[f]) == o.n_bits and np.array_equal(out[f, :(o.n_bits + 7) // 8].cpu().numpy(), o.bits), f
+    assert np.array_equal(res[1][0], bits) and torch.equal(res[1][1], out)
 
 
 def test_batch_at_worst_case_capacity_is_accepted(jpeg, enc):
