@@ -350,7 +350,7 @@ __device__ __forceinline__ int dc_predictor(const uint32_t* __restrict__ coefs_f
 #endif
 // Bit-assembly window of k_emit / k_merge: 4096 words = 16 KiB = 131072 bits = 682 bits per unit on
 // average (tiles with more bits take the direct-to-memory path).  With its 17,280 B of LDS one merge
-// workgroup fits on a CU next to two workgroups of k_screen_encode (2 x 72,832 B of 160 KiB).
+// workgroup fits on a CU next to two workgroups of k_screen_encode (2 x 72,576 B of 160 KiB, in 1280-byte granules).
 constexpr uint32_t kEmitLdsWords = MI355_EMIT_LDS_WORDS;
 // k_merge's half-size window (two workgroups per CU beside the block encode: 2 x 8,896 B within the same 17,920 B)
 constexpr uint32_t kEmitLdsWordsSmall = 2000;

@@ -406,9 +406,10 @@ struct WaveArena {
 // (run,size) table.  Bits are packed with 32-bit funnel shifts.  LDS reads are
 // software-pipelined two symbols ahead.  Same bits as walk_ac().
 // ----------------------------------------------------------------------------
-// The kernel's LDS is kept at 72,832 B per workgroup (24 slot rows, no fp64 threshold table), so that
-// next to the two resident workgroups of a CU one workgroup of k_merge (17,280 B) or k_dc_heads still
-// fits: another stream's tail kernels then run under this kernel instead of waiting for it.
+// The kernel's LDS is kept at 72,576 B per workgroup (24 slot rows, no fp64 threshold table), so that next to the two
+// resident workgroups of a CU one workgroup of k_merge with the full window (17,280 B) or two with the half window that
+// batches run (2 x 8,896 B), or k_dc_heads, still fit: another stream's tail kernels then run under this kernel instead of
+// waiting for it (tests/test_kernel_budget.py checks the budget on the built library).
 #ifndef MI355_SLOT_ROWS
 #define MI355_SLOT_ROWS 24
 #endif

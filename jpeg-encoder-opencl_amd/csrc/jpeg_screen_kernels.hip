@@ -54,8 +54,10 @@ constexpr uint32_t kEncWaves = 4;
 // MODE 0: strict (the reference's arithmetic); 1: standard 4:4:4; 2: standard 4:2:0 (tile = 64 MCUs,
 // six passes: luma quarter-tiles 0..3 -- unit u of pass s is block k = u & 3 of MCU 16 s + u / 4, i.e.
 // the scan order of the luma blocks -- then Cb, Cr with one block per MCU).
-// At most 224 registers (the attribute counts in units of two on gfx90a and later: 112): two workgroups of this kernel per CU leave 64 per SIMD lane, which is what the tail kernels of the
-// part in front need to run BESIDE it (k_merge: two waves of 32 on a SIMD; above 224 batched calls lose a fifth).
+// At most 224 registers (the attribute counts in units of two on gfx90a and later: 112): two workgroups of this kernel
+// per CU leave 64 per SIMD lane, which is what the tail kernels of the part in front need to run BESIDE it (k_merge: two
+// waves, 32 allocated each; one register granule more and batched calls lose a fifth to a quarter: DESIGN.md §4.5,
+// tests/test_kernel_budget.py).
 template <bool PROBE, int MODE>
 __attribute__((amdgpu_num_vgpr(112))) __global__ void __launch_bounds__(256, 2)
     k_screen_encode(Geom g, uint32_t n_frames, const uint8_t* __restrict__ rgb, ScreenParams sp) {
