@@ -215,10 +215,10 @@ def other_configs_leg(jpeg, enc, torch, dev, stream):
             4, "DCT/quant HBM-roofline stress (BASELINE): 14.7 bit/px; values beyond the whole-symbol table in nearly every pass "
                "(passes_in_general_walk_loop), no string beyond its 24-word LDS slot (strings_walked_twice_per_unit)")
         c = golden_case("lcg_3840x2160_s1_q50_cds")
-        run("the headline workload at 100 frames per call: parts of unequal size (16 and 17 frames)", W, H, 100, 50, jpeg.F_DEFAULT, lcg(1),
+        run("the headline workload at 100 frames per call (a batch size other than the tuned one)", W, H, 100, 50, jpeg.F_DEFAULT, lcg(1),
             {"n_bits": c["n_bits"], "sha_ascii": c["sha256_ascii_bits"], "cap": 8 << 20, "what": "tests/golden/cases.json lcg_3840x2160_s1_q50_cds (reference build)"},
-            6, "a batch that does not divide evenly: a part's merge can outlast the block encode it runs beside, and until round 4 "
-               "(one k_merge workgroup per CU) the next launch's persistent workgroups then waited for LDS -- 235 instead of 256 Gpixel/s")
+            6, "until round 4 (one k_merge workgroup per CU, equal parts) a batch that did not divide evenly lost 8 %: a part's merge "
+               "outlasted the block encode it ran beside and the next launch's persistent workgroups waited for LDS (DESIGN.md 4.5)")
         c = golden_case("fruit_tiled_3840x2160_q50_cds")
         run("natural statistics, strict: fruit.ppm tiled to 3840x2160, 128 frames per call, q50, chroma averaging on", W, H, 128, 50,
             jpeg.F_DEFAULT, fruit, {"n_bits": c["n_bits"], "sha_ascii": c["sha256_ascii_bits"], "cap": 8 << 20,
