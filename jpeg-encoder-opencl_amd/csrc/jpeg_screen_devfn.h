@@ -791,7 +791,7 @@ __device__ __forceinline__ void screen_quantise(const v4i (&A)[kLookDigits], con
 // screen had produced them.  All lanes must be active.
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ void exact_unit_wave(const uint8_t* __restrict__ f, const Geom& g, uint32_t chan, uint32_t bx,
-                                                uint32_t by, const double* __restrict__ qd, double* lds /* 65 doubles */,
+                                                uint32_t by, const double* __restrict__ qd, double* lds /* 65 doubles + the 64 of the cosine table from lds[72] */,
                                                 i16a* row /* the unit's column of the row buffer */, uint32_t* mlo,
                                                 uint32_t* mhi, uint32_t lane) {
     static constexpr double kCos[8][8] = MI355_COS_TABLE;
@@ -801,12 +801,18 @@ __device__ __forceinline__ void exact_unit_wave(const uint8_t* __restrict__ f, c
     const uint32_t smp = sample_generic(f, g, avg, bx * 8 + x, by * 8 + y, csc_k(chan, 0), csc_k(chan, 1), csc_k(chan, 2),
                                         csc_k(chan, 3));
     double p = (double)((int)smp - 128);  // quirk Q4
+    // the cosine table through LDS (behind the 65 doubles of the steps): read from memory inside the loops, every one of the 64
+    // dependent steps waited for a load -- and for every store the wave had in flight -- before its first multiply: 39 us per
+    // unit, of which the sums are the smaller part (round 4, tools/slow_frames_probe.py)
+    double* const tab = lds + 72;
+    tab[lane] = kCos[y][x];
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
     for (uint32_t u = 0; u < 8; ++u) {
-        const double cxu = kCos[x][u];
+        const double cxu = tab[x * 8 + u];
 #pragma unroll 1
         for (uint32_t v = 0; v < 8; ++v) {
-            lds[lane] = (p * cxu) * kCos[y][v];
+            lds[lane] = (p * cxu) * tab[y * 8 + v];
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
                 double sum = 0.0;
