@@ -613,7 +613,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     }
     // Part boundaries: part i = frames [cut[i], cut[i + 1]).
     //
-    // Tapered (the ratio of a part to the part in front, in per cent; batches of five parts or more): every part's tail
+    // Tapered (the ratio of a part to the part in front, in per cent; batches of four parts or more): every part's tail
     // kernels run under the NEXT part's block encode -- except the last part's, which nothing hides -- so the batch should
     // end on a short part; but a part's merge, beside an encode launch, takes 0.6 of the time that launch needs for the
     // same number of frames (strict mode, q50: 19 against 31 us per 4K frame), so a part may not be much shorter than that
@@ -635,7 +635,7 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     const uint64_t frame_px = (uint64_t)g.W * g.H;
     bool tapered = false;
     const uint32_t nparts_equal = nparts;
-    if (taper && nparts >= 5) {
+    if (taper && nparts >= 4) {
         std::vector<uint32_t> rev;  // sizes from the last part backwards
         double x = (double)(((1ull << 25) + frame_px / 2) / frame_px);
         if (x < 1.0) x = 1.0;

@@ -1140,7 +1140,7 @@ def test_parts_that_share_workspace_sets(jpeg, monkeypatch):
 
 
 def test_tapered_parts_give_the_bits_of_equal_parts(jpeg, monkeypatch):
-    """Batches of five parts or more run in parts of falling size, each with a workspace set of its own size (strict mode's
+    """Batches of four parts or more run in parts of falling size, each with a workspace set of its own size (strict mode's
     default).  96 4K frames under three partitions -- the default taper (70), a steep one (45: a first part
     that is smaller than the second) and equal parts -- must give the same bytes, and the reference build's goldens for the
     frames that have one.  (test_parts_that_share_workspace_sets covers the fall-back to equal parts with shared sets.)"""
