@@ -715,7 +715,15 @@ int run_screened(mi355_jpeg_ctx* c, const Geom& g, uint32_t n_frames, const uint
     if ((e = ensure(c->d_meta, c->meta_cap, meta_off.back()))) return e;
     if ((e = ensure(c->d_arena, c->arena_cap, arena_off.back()))) return e;
     if (nparts > 1 && !c->side) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        // The side stream at the highest priority.  Not for the order of dispatch (its kernels are small and take what they
+        // get) but for the hardware queue: HIP hands its (four) hardware queues to streams in turn, and in a process that
+        // holds more streams than that -- RCCL creates several when a process group is set up -- a default-priority side
+        // stream can land on the queue of the caller's stream, where the tail kernels run BETWEEN the block-encode launches
+        // instead of beside them: the N > 1 path of bench.py ran 13 % below the single process for that reason (229 against
+        // 261 Gpixel/s per GPU, gpurun reh2).  Priority streams have queues of their own.
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // hi = the numerically smallest = highest priority
+        HIP_TRY(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_hi));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_half, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
     }
