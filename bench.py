@@ -235,13 +235,16 @@ def other_configs_leg(jpeg, enc, torch, dev, stream):
 
 
 def kernel_sources_sha():
-    """Identifies the kernel sources a PMC measurement belongs to (the GPU box has no .git)."""
+    """Identifies the kernel sources -- and the Makefile with the compiler flags -- a PMC measurement belongs to (the GPU box
+    has no .git)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "jpeg-encoder-opencl_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h", ".cpp")):
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
+    h.update(b"Makefile")
+    h.update(open(os.path.join(ROOT, "jpeg-encoder-opencl_amd", "Makefile"), "rb").read())
     return h.hexdigest()[:16]
 
 
