@@ -364,6 +364,69 @@ __device__ __forceinline__ void std_rowpair_mfma(const RawChunk (&X)[4], const v
             pk[2 * r + h] = pack_byte2(sv);
         }
 }
+// ---- strict mode: the reference's conversion on the matrix units (whole tiles inside the image) ----
+// The integer numerators of csc_int -- 299 R + 587 G + 114 B, and (128e6 + ...) / 32 for chroma -- formed exactly by two
+// matrix instructions per four pixels (two balanced base-256 digits of the coefficients, fragment sets kCscSets.. of
+// jpeg_tables.h) instead of four vector instructions per pixel (byte permute, byte extract, multiply-add, dot product);
+// the division, the remainder test of luma and its rare fp64 evaluation are those of convert_rowpair.  w = the raw row
+// pair (2 x 24 bytes); the chunk of half 0 is {w0, w1, w2, K}, that of half 1 {K, w3, w4, w5}: the fourth dword carries the
+// constant term (every byte kCscKByte; the operand bytes are x - 128 = x ^ 0x80, which the same term makes up for).
+template <int CHAN>
+__device__ __forceinline__ void strict_rowpair_mfma(const uint32_t (&w)[12], const v4i (&F)[4], bool avg, uint32_t (&pk)[4]) {
+    constexpr int kK = kCscKByte * 0x01010101;
+    uint32_t val[2][8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int x0 = (int)(w[r * 6 + 3 * h] ^ 0x80808080u), x1 = (int)(w[r * 6 + 3 * h + 1] ^ 0x80808080u),
+                      x2 = (int)(w[r * 6 + 3 * h + 2] ^ 0x80808080u);
+            const v4i b = h ? v4i{kK, x0, x1, x2} : v4i{x0, x1, x2, kK};
+            const v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[2 * h], b, v4i{0, 0, 0, 0}, 0, 0, 0);
+            const v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[2 * h + 1], b, v4i{0, 0, 0, 0}, 0, 0, 0);
+            uint32_t rem[4];
+#pragma unroll
+            for (int xx = 0; xx < 4; ++xx) {
+                const uint32_t s = (uint32_t)((a1[xx] << 8) + a0[xx]);
+                if constexpr (CHAN == 0) {
+                    const uint32_t y = div1000(s);
+                    val[r][4 * h + xx] = y;
+                    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(rem[xx]) : "v"(y), "s"(-1000), "v"(s));
+                } else {
+                    val[r][4 * h + xx] = div31250(s);
+                }
+            }
+            if constexpr (CHAN == 0) {
+                const uint32_t m01 = rem[0] < rem[1] ? rem[0] : rem[1], m23 = rem[2] < rem[3] ? rem[2] : rem[3];
+                if (wave_any((m01 < m23 ? m01 : m23) == 0u)) {
+#pragma unroll
+                    for (int xx = 0; xx < 4; ++xx)
+                        if (rem[xx] == 0u) {
+                            const int o = 3 * (4 * h + xx);
+                            const uint32_t R = (w[r * 6 + (o >> 2)] >> (8 * (o & 3))) & 255u, G = (w[r * 6 + ((o + 1) >> 2)] >> (8 * ((o + 1) & 3))) & 255u,
+                                           B = (w[r * 6 + ((o + 2) >> 2)] >> (8 * ((o + 2) & 3))) & 255u;
+                            val[r][4 * h + xx] = csc1(R, G, B, 0.299, 0.587, 0.114, 0.0);
+                        }
+                }
+            }
+        }
+    if (avg) {
+        uint32_t m[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) m[x] = (val[0][2 * x] + val[0][2 * x + 1] + val[1][2 * x] + val[1][2 * x + 1]) >> 2;
+        pk[0] = __builtin_amdgcn_perm(m[1], m[0], 0x04040000u);
+        pk[1] = __builtin_amdgcn_perm(m[3], m[2], 0x04040000u);
+        pk[2] = pk[0];
+        pk[3] = pk[1];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                pk[r * 2 + h] = val[r][4 * h] | (val[r][4 * h + 1] << 8) | (val[r][4 * h + 2] << 16) | (val[r][4 * h + 3] << 24);
+    }
+}
+
 // ----------------------------------------------------------------------------
 // device-side parameter block
 // ----------------------------------------------------------------------------

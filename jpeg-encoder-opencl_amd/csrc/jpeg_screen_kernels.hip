@@ -67,10 +67,13 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ void __launch_bounds__(256, 2)
     // scheme for its chroma passes was built and measured at -1.5 % (profiles/r03_f_*) -- a matrix
     // instruction costs the issuing wave what 2.5 plain VALU instructions cost, the fixed-point form needs only four of
     // those per pixel, and the fragments' registers push the kernel to the limit beyond which the tail kernels stop
-    // running beside it.  Strict mode does not either (round 4, gpurun r4cs-r4cu): the reference's integer numerators on
-    // the matrix units are bit-exact and 9 % SLOWER -- of the four vector instructions a pixel saves, the shift-add that joins
-    // the two digits and the x ^ 0x80 of the operand bytes take back almost two, and the matrix results arrive late.
+    // running beside it.
     constexpr bool kCscMfma = MODE == 1;
+    // Strict mode forms the reference's integer numerators on the matrix units too (strict_rowpair_mfma); division, luma's
+    // remainder test and the chroma means stay on the vector units.  Bit-exact either way; which is faster depends on the
+    // instruction scheduling: under the backend's default strategy the matrix form lost 9 % (gpurun r4cu: its results arrive
+    // late in a phase with nothing else to issue), under iterative-ilp it wins 1.2 % (269.8 against 266.5, gpurun r4cs2).
+    constexpr bool kCscMfmaStrict = MODE == 0;
     __shared__ uint32_t s_tbuf_all[kEncWaves][kRowWords];          // zig-zag rows, int16 [position][unit] (jpeg_screen_devfn.h)
     __shared__ alignas(16) uint32_t s_slot_all[kEncWaves][(kSlotRows + 1) * 64];  // AC strings [word][lane] + dump row
     __shared__ uint32_t s_mask_all[kEncWaves][2][64];              // non-zero masks (lo, hi)
@@ -232,6 +235,7 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ void __launch_bounds__(256, 2)
             load_csc_fragments(sp, lane, (int)ps.chan * 4, F);
             load_std_rowpair(pf, g, ps.b0 & 0xffffu, ps.b0 >> 16, gq, Xn);
         } else {
+            if constexpr (kCscMfmaStrict) load_csc_fragments(sp, lane, kCscSets + (int)ps.chan * 4, F);
             if (!chroma420) load_raw_rowpair(pf, g, ps.b0 & 0xffffu, ps.b0 >> 16, gq, raw);
         }
     };
@@ -305,9 +309,14 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ void __launch_bounds__(256, 2)
 #pragma unroll
                 for (int i = 0; i < 12; ++i) rp[i] = raw[i];
                 if (j < 3) load_raw_rowpair(f, g, cur.bxy(j + 1) & 0xffffu, cur.bxy(j + 1) >> 16, gq, raw);  // (two pairs in flight: -1 %)
-                if (comp == 0) convert_rowpair<0, STD>(rp, false, pk);
-                else if (comp == 1) convert_rowpair<1, STD>(rp, avg, pk);
-                else convert_rowpair<2, STD>(rp, avg, pk);
+                if constexpr (kCscMfmaStrict) {
+                    if (comp == 0) strict_rowpair_mfma<0>(rp, F, false, pk);
+                    else strict_rowpair_mfma<1>(rp, F, avg, pk);
+                } else {
+                    if (comp == 0) convert_rowpair<0, STD>(rp, false, pk);
+                    else if (comp == 1) convert_rowpair<1, STD>(rp, avg, pk);
+                    else convert_rowpair<2, STD>(rp, avg, pk);
+                }
             } else {
                 if (comp == 0) generic_rowpair<0, STD>(f, g, false, bx, by, gq, pk);
                 else if (comp == 1) generic_rowpair<1, STD>(f, g, avg, bx, by, gq, pk);
