@@ -369,21 +369,23 @@ __device__ __forceinline__ void std_rowpair_mfma(const RawChunk (&X)[4], const v
 // matrix instructions per four pixels (two balanced base-256 digits of the coefficients, fragment sets kCscSets.. of
 // jpeg_tables.h) instead of four vector instructions per pixel (byte permute, byte extract, multiply-add, dot product);
 // the division, the remainder test of luma and its rare fp64 evaluation are those of convert_rowpair.  w = the raw row
-// pair (2 x 24 bytes); the chunk of half 0 is {w0, w1, w2, K}, that of half 1 {K, w3, w4, w5}: the fourth dword carries the
-// constant term (every byte kCscKByte; the operand bytes are x - 128 = x ^ 0x80, which the same term makes up for).
+// pair (2 x 24 bytes); each half of a row is one operand {three dwords = four pixels, a fourth the fragments ignore}: the
+// fourth is left undefined on purpose, so that the register allocator can take whatever lies behind the three (a defined
+// filler cost eleven moves per row pair).  The operand bytes are x - 128 = x ^ 0x80; the constant term, and what the - 128
+// takes away, enter through the accumulator input of the low digit (F = {digit 0, digit 1}, cst = kCscStrictC splat).
 template <int CHAN>
-__device__ __forceinline__ void strict_rowpair_mfma(const uint32_t (&w)[12], const v4i (&F)[4], bool avg, uint32_t (&pk)[4]) {
-    constexpr int kK = kCscKByte * 0x01010101;
+__device__ __forceinline__ void strict_rowpair_mfma(const uint32_t (&w)[12], const v4i (&F)[2], const v4i& cst, bool avg, uint32_t (&pk)[4]) {
     uint32_t val[2][8];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int x0 = (int)(w[r * 6 + 3 * h] ^ 0x80808080u), x1 = (int)(w[r * 6 + 3 * h + 1] ^ 0x80808080u),
-                      x2 = (int)(w[r * 6 + 3 * h + 2] ^ 0x80808080u);
-            const v4i b = h ? v4i{kK, x0, x1, x2} : v4i{x0, x1, x2, kK};
-            const v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[2 * h], b, v4i{0, 0, 0, 0}, 0, 0, 0);
-            const v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[2 * h + 1], b, v4i{0, 0, 0, 0}, 0, 0, 0);
+            int dontcare;
+            asm volatile("" : "=v"(dontcare));  // no instruction: an undefined register (volatile: one per operand, not one shared by copies)
+            const v4i b = v4i{(int)(w[r * 6 + 3 * h] ^ 0x80808080u), (int)(w[r * 6 + 3 * h + 1] ^ 0x80808080u),
+                              (int)(w[r * 6 + 3 * h + 2] ^ 0x80808080u), dontcare};
+            const v4i a0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[0], b, cst, 0, 0, 0);
+            const v4i a1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(F[1], b, v4i{0, 0, 0, 0}, 0, 0, 0);
             uint32_t rem[4];
 #pragma unroll
             for (int xx = 0; xx < 4; ++xx) {

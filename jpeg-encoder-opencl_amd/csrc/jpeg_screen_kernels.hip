@@ -235,7 +235,13 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ void __launch_bounds__(256, 2)
             load_csc_fragments(sp, lane, (int)ps.chan * 4, F);
             load_std_rowpair(pf, g, ps.b0 & 0xffffu, ps.b0 >> 16, gq, Xn);
         } else {
-            if constexpr (kCscMfmaStrict) load_csc_fragments(sp, lane, kCscSets + (int)ps.chan * 4, F);
+            if constexpr (kCscMfmaStrict) {  // the pass's two digit sets (F[0], F[1]) travel with its first rows
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint4 t = sp.csc_frag[(kCscSets + (int)ps.chan * 2 + i) * 64 + lane];
+                    F[i] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+                }
+            }
             if (!chroma420) load_raw_rowpair(pf, g, ps.b0 & 0xffffu, ps.b0 >> 16, gq, raw);
         }
     };
@@ -310,8 +316,9 @@ __attribute__((amdgpu_num_vgpr(112))) __global__ void __launch_bounds__(256, 2)
                 for (int i = 0; i < 12; ++i) rp[i] = raw[i];
                 if (j < 3) load_raw_rowpair(f, g, cur.bxy(j + 1) & 0xffffu, cur.bxy(j + 1) >> 16, gq, raw);  // (two pairs in flight: -1 %)
                 if constexpr (kCscMfmaStrict) {
-                    if (comp == 0) strict_rowpair_mfma<0>(rp, F, false, pk);
-                    else strict_rowpair_mfma<1>(rp, F, avg, pk);
+                    const v4i (&F2)[2] = reinterpret_cast<const v4i (&)[2]>(F);
+                    if (comp == 0) strict_rowpair_mfma<0>(rp, F2, splat4(kCscStrictC[0]), false, pk);
+                    else strict_rowpair_mfma<1>(rp, F2, splat4(kCscStrictC[1]), avg, pk);  // (the fragments say which chroma channel)
                 } else {
                     if (comp == 0) convert_rowpair<0, STD>(rp, false, pk);
                     else if (comp == 1) convert_rowpair<1, STD>(rp, avg, pk);

@@ -72,13 +72,13 @@ constexpr int kStdCsc420[2][3] = {{-2765, -5427, 8192}, {8192, -6860, -1332}};
 // consumed by jpeg_screen_devfn.h: std_rowpair_mfma): set ((chan * 2 + half) * 2 + digit), 12 sets.
 constexpr int kCscSets = 12;
 // Strict mode (the reference's conversion, utils.cpp:92-110) on the matrix units: the integer numerators of
-// jpeg_screen_devfn.h's csc_int -- Y: 299 R + 587 G + 114 B; Cb, Cr: the numerators over 1e6 divided by 32, + 4000000 --
-// as 12 more fragment sets of the same shape, sets kCscSets + ((chan * 2 + half) * 2 + digit).  The constant term (and the
-// 128 * sum of the coefficients that the x - 128 operand bytes take away) enters through the chunk's unused dword, which the
-// kernel fills with kCscKByte in every byte: digit 1 (weight 256) carries kCscStrictK1[chan] there, 125 * K1 * 256 =
-// 128000 (luma: 128 * 1000) or 4000000 (chroma: the rows sum to zero).
+// jpeg_screen_devfn.h's csc_int -- Y: 299 R + 587 G + 114 B; Cb, Cr: the numerators over 1e6 divided by 32 -- as 6 more
+// fragment sets of the same shape, sets kCscSets + chan * 2 + digit: four pixels at chunk bytes 3 r .. 3 r + 2 (both halves
+// of a block row are presented that way: {w0, w1, w2, -} and {w3, w4, w5, -}, the fourth dword has no coefficients).  The
+// constant term -- 4000000 for chroma, and the 128 * sum of the coefficients that the x - 128 operand bytes take away:
+// 128000 for luma, 0 for chroma, whose rows sum to zero -- enters through the accumulator input (kCscStrictC).
 constexpr int kCscStrict[3][3] = {{299, 587, 114}, {-5273, -10352, 15625}, {15625, -13084, -2541}};
-constexpr int kCscKByte = 125;
-constexpr int kCscStrictK1[3] = {4, 125, 125};
+constexpr int kCscStrictC[3] = {128000, 4000000, 4000000};
+constexpr int kCscStrictSets = 6;
 
 }  // namespace mi355

@@ -347,7 +347,7 @@ int upload_afrag(mi355_jpeg_ctx* c) {
 // the chunk contributes to output r), laid out as fragment lane (m, kq) = W[m & 3][.] if (m >> 2) == kq, else zero.
 // Coefficients are split into two balanced base-256 digits: c = 256 d1 + d0, d0 in -128..127.
 int upload_csc_frag(mi355_jpeg_ctx* c) {
-    std::vector<int8_t> h((size_t)2 * kCscSets * 64 * 16, 0);
+    std::vector<int8_t> h((size_t)(kCscSets + kCscStrictSets) * 64 * 16, 0);
     auto put = [&](int set, auto&& coef /* (r, t) -> coefficient or 0 */) {
         for (int digit = 0; digit < 2; ++digit)
             for (int lane = 0; lane < 64; ++lane) {
@@ -368,16 +368,12 @@ int upload_csc_frag(mi355_jpeg_ctx* c) {
                 const int o = t - (half ? 4 : 0) - 3 * r;
                 return o >= 0 && o < 3 ? kStdCsc[chan][o] : 0;
             });
+    // strict mode: the reference's integer numerators, one pair of digit sets per channel (jpeg_tables.h)
     for (int chan = 0; chan < 3; ++chan)
-        for (int half = 0; half < 2; ++half) {
-            const int set = kCscSets + (chan * 2 + half) * 2;
-            put(set, [&](int r, int t) {
-                const int o = t - (half ? 4 : 0) - 3 * r;
-                return o >= 0 && o < 3 ? kCscStrict[chan][o] : 0;
-            });
-            for (int lane = 0; lane < 64; ++lane)
-                if (((lane & 15) >> 2) == (lane >> 4)) h[((size_t)(set + 1) * 64 + lane) * 16 + (half ? 0 : 12)] = (int8_t)kCscStrictK1[chan];
-        }
+        put(kCscSets + chan * 2, [&](int r, int t) {
+            const int o = t - 3 * r;
+            return o >= 0 && o < 3 ? kCscStrict[chan][o] : 0;
+        });
     HIP_TRY(hipMemcpy(c->d_afrag + 2 * kAfragBytes / sizeof(uint4), h.data(), h.size(), hipMemcpyHostToDevice));
     return MI355_OK;
 }
@@ -930,7 +926,7 @@ static int create_body(int device_id, mi355_jpeg_ctx** out){
         hipMalloc((void**)&c->d_qzz, 128 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut, 2048 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->d_status, sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_afrag, 2 * kAfragBytes + (size_t)2 * kCscSets * 1024) != hipSuccess ||
+        hipMalloc((void**)&c->d_afrag, 2 * kAfragBytes + (size_t)(kCscSets + kCscStrictSets) * 1024) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst, 512 * sizeof(double)) != hipSuccess ||
         hipMalloc((void**)&c->d_qconst_f, 512 * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&c->d_lut2, 4 * 66 * 16 * sizeof(uint32_t)) != hipSuccess ||
