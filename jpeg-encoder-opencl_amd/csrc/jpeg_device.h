@@ -35,7 +35,7 @@ inline size_t unit_off_words(const Geom& g) { return (size_t)g.tiles * 192; }
 // Device pointers of the screened (integer-MFMA) pipeline, jpeg_screen_kernels.hip.
 struct ScreenParams {
     const uint4* afrag;     // [4 row tiles][5 digits][64 lanes] 16 int8: MFMA A fragments of the fixed-point map
-    const uint4* csc_frag;  // standard mode: [28 sets][64 lanes] 16 int8: MFMA A fragments of the colour conversion (jpeg_tables.h)
+    const uint4* csc_frag;  // [kCscSets standard-mode sets + kCscStrictSets strict-mode sets][64 lanes] 16 int8: MFMA A fragments of the colour conversion (jpeg_tables.h)
     const double* qconst;   // [2 channel types][64 zig-zag positions][4] = {s1, thr1, s2, thr2}
     const float* qconst_f;  // [2][16 groups of 4 positions][8] = {2^-23/Q x4, first-look threshold x4}
     const double* qd;       // [2][64] quantiser divisors as doubles, natural order
